@@ -1,0 +1,77 @@
+"""ctypes binding of libmgx.so -- mirrors include/*.h one to one."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class MgxError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmgx.so")
+
+
+class PairHMMInput(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint64), ("read_off", C.c_void_p), ("bases", C.c_void_p),
+        ("qual", C.c_void_p), ("ins", C.c_void_p), ("del_", C.c_void_p), ("gcp", C.c_void_p),
+        ("n_haps", C.c_uint64), ("hap_off", C.c_void_p), ("hap_bases", C.c_void_p),
+        ("n_pairs", C.c_uint64), ("pair_read", C.c_void_p), ("pair_hap", C.c_void_p),
+    ]
+
+
+class PairHMMStats(C.Structure):
+    _fields_ = [
+        ("n_pairs", C.c_uint64), ("cells", C.c_uint64), ("alg_bytes", C.c_uint64),
+        ("n_rerun_f64", C.c_uint64), ("n_launches_f32", C.c_uint32), ("n_launches_f64", C.c_uint32),
+        ("ms_f32", C.c_float), ("ms_f64", C.c_float), ("ms_f32_dominant", C.c_float),
+        ("dominant_cells", C.c_uint64), ("dominant_alg_bytes", C.c_uint64),
+        ("dominant_kernel", C.c_char * 64),
+    ]
+
+
+# every symbol include/mgx_pairhmm.h declares: name -> (restype, argtypes)
+PAIRHMM_SYMBOLS = {
+    "mgx_last_error": (C.c_char_p, []),
+    "mgx_pairhmm_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
+    "mgx_pairhmm_destroy": (None, [C.c_void_p]),
+    "mgx_pairhmm_compute": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_void_p]),
+    "mgx_pairhmm_batch_create": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.POINTER(C.c_void_p)]),
+    "mgx_pairhmm_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_batch_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_batch_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PairHMMStats)]),
+    "mgx_pairhmm_batch_destroy": (None, [C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_sync": (C.c_int, [C.c_void_p]),
+    "mgx_pairhmm_table_f32": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mgx_pairhmm_table_f64": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+}
+
+SYMBOLS = dict(PAIRHMM_SYMBOLS)
+
+
+def load():
+    """Loads libmgx.so (never falls back to anything else)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MgxError(
+            f"{path} is missing: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)       # AttributeError if the ABI and the header diverge
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mgx_last_error()
+        raise MgxError(f"libmgx error {rc}: {msg.decode() if msg else ''}")

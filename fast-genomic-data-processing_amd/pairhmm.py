@@ -1,0 +1,109 @@
+"""Host-side handle on the PairHMM C ABI (include/mgx_pairhmm.h).
+
+The argument layout is the flattened form of the reference's ``testcase`` list
+(deepmutect/Mutect2Cpp-master/src/intel/pairhmm/pairhmm_common.h:45-57) as built by
+VectorLoglessPairHMM::computeLog10Likelihoods (utils/pairhmm/VectorLoglessPairHMM.cpp:71-119).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+
+FORCE_DOUBLE = 1
+TIMING = 2
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _as(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a
+
+
+def make_input(d):
+    """dict of packed arrays (see synth.gen_pairhmm_pairs) -> (PairHMMInput, keepalive)."""
+    keep = dict(
+        read_off=_as(d["read_off"], np.uint64), bases=_as(d["bases"], np.uint8),
+        qual=_as(d["qual"], np.uint8), ins=_as(d["ins"], np.uint8), dele=_as(d["dele"], np.uint8),
+        gcp=_as(d["gcp"], np.uint8), hap_off=_as(d["hap_off"], np.uint64),
+        hap_bases=_as(d["hap_bases"], np.uint8), pair_read=_as(d["pair_read"], np.uint32),
+        pair_hap=_as(d["pair_hap"], np.uint32))
+    inp = native.PairHMMInput(
+        n_reads=len(keep["read_off"]) - 1, read_off=_ptr(keep["read_off"]), bases=_ptr(keep["bases"]),
+        qual=_ptr(keep["qual"]), ins=_ptr(keep["ins"]), del_=_ptr(keep["dele"]), gcp=_ptr(keep["gcp"]),
+        n_haps=len(keep["hap_off"]) - 1, hap_off=_ptr(keep["hap_off"]), hap_bases=_ptr(keep["hap_bases"]),
+        n_pairs=len(keep["pair_read"]), pair_read=_ptr(keep["pair_read"]), pair_hap=_ptr(keep["pair_hap"]))
+    return inp, keep
+
+
+class PairHMMBatch:
+    def __init__(self, engine, d):
+        self.engine = engine
+        self.n_pairs = len(d["pair_read"])
+        inp, keep = make_input(d)
+        h = C.c_void_p()
+        native.check(engine.lib.mgx_pairhmm_batch_create(engine.ctx, C.byref(inp), C.byref(h)))
+        self.h = h
+
+    def run(self):
+        native.check(self.engine.lib.mgx_pairhmm_batch_run(self.engine.ctx, self.h))
+
+    def results(self, with_flags=False):
+        out = np.empty(self.n_pairs, dtype=np.float64)
+        used = np.zeros(self.n_pairs, dtype=np.uint8)
+        native.check(self.engine.lib.mgx_pairhmm_batch_results(self.engine.ctx, self.h, _ptr(out), _ptr(used)))
+        return (out, used) if with_flags else out
+
+    def stats(self):
+        st = native.PairHMMStats()
+        native.check(self.engine.lib.mgx_pairhmm_batch_stats(self.engine.ctx, self.h, C.byref(st)))
+        return {k: (getattr(st, k).decode() if k == "dominant_kernel" else getattr(st, k))
+                for k, _ in native.PairHMMStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.engine.lib.mgx_pairhmm_batch_destroy(self.engine.ctx, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PairHMMEngine:
+    """One context = one device + one compute stream (use one per worker thread)."""
+
+    def __init__(self, device=0, flags=0):
+        self.lib = native.load()
+        ctx = C.c_void_p()
+        native.check(self.lib.mgx_pairhmm_create(device, flags, C.byref(ctx)))
+        self.ctx = ctx
+
+    def compute(self, d):
+        """One shot: returns log10 likelihoods, one per test case."""
+        inp, keep = make_input(d)
+        out = np.empty(inp.n_pairs, dtype=np.float64)
+        native.check(self.lib.mgx_pairhmm_compute(self.ctx, C.byref(inp), _ptr(out)))
+        return out
+
+    def batch(self, d):
+        return PairHMMBatch(self, d)
+
+    def sync(self):
+        native.check(self.lib.mgx_pairhmm_sync(self.ctx))
+
+    def close(self):
+        if self.ctx:
+            self.lib.mgx_pairhmm_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

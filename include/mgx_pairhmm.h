@@ -1,0 +1,115 @@
+/*
+ * mgx_pairhmm.h -- C ABI of the MI355X PairHMM likelihood engine (libmgx.so).
+ *
+ * Drop-in seam: this is what the reference's ex-JNI "native" layer would bind instead of the
+ * Intel GKL AVX kernels.  Reference interface replaced (paths relative to
+ * deepmutect/Mutect2Cpp-master/src/):
+ *
+ *   mgx_pairhmm_create            <- initNative(bool use_double, int max_threads)
+ *                                    intel/pairhmm/IntelPairHmm.h:37, IntelPairHmm.cc:202-256
+ *   mgx_pairhmm_compute           <- computeLikelihoodsNative(vector<testcase>&, vector<double>&)
+ *                                    intel/pairhmm/IntelPairHmm.h:39, IntelPairHmm.cc:259-293
+ *                                    and computeLikelihoodsNative_concurrent_i  (:332-351), the
+ *                                    per-test-case loop of VectorLoglessPairHMM.cpp:118-119
+ *   mgx_pairhmm_batch_*           <- the same call split into upload / run / download so a caller
+ *                                    can keep several active regions in flight (replaces the
+ *                                    tail-phase work sharing, IntelPairHmm.cc:296-330, 659-693)
+ *   mgx_pairhmm_destroy           <- doneNative (IntelPairHmm.cc:190-198, a no-op there)
+ *
+ * A "test case" (pairhmm_common.h:45-57: haplen, hap, ReadForPairHMM) is flattened to indices
+ * into packed read / haplotype arrays so that nothing but plain pointers and sizes crosses the
+ * boundary.  Per-read inputs are the five byte arrays ReadForPairHMM's constructor takes
+ * (haplotypecaller/ReadForPairHMM.cpp:18-38): bases, base quals, insertion GOP, deletion GOP,
+ * gap-continuation penalty.  Every quality byte is masked with 127 on the device exactly as the
+ * reference does; bases are ASCII, any byte other than A/C/G/T/N is treated as 'A'
+ * (pairhmm_common.h:75-81).
+ *
+ * All functions return 0 on success or a negative errno-style code; no exception crosses the
+ * boundary.  mgx_last_error() returns a thread-local message for the last failure.
+ * Buffers passed in are caller-owned and only read during the call; the library never frees
+ * them.  A context is bound to one device and one compute stream and may be used by one host
+ * thread at a time; use one context per worker thread (the reference also keeps one
+ * VectorLoglessPairHMM per worker thread, Mutect2Engine.cpp:27-29).
+ */
+#ifndef MGX_PAIRHMM_H
+#define MGX_PAIRHMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_pairhmm mgx_pairhmm_t;
+typedef struct mgx_pairhmm_batch mgx_pairhmm_batch_t;
+
+/* flags for mgx_pairhmm_create */
+#define MGX_PAIRHMM_FORCE_DOUBLE 1u /* PairHMMNativeArgumentCollection.useDoublePrecision */
+#define MGX_PAIRHMM_TIMING       2u /* record HIP events around every kernel launch */
+
+/* Packed host-side description of one batch of test cases. */
+typedef struct mgx_pairhmm_input {
+    uint64_t n_reads;
+    const uint64_t* read_off;  /* [n_reads + 1] prefix offsets into the five read arrays */
+    const uint8_t* bases;      /* ASCII read bases */
+    const uint8_t* qual;       /* base qualities */
+    const uint8_t* ins;        /* insertion gap-open penalties */
+    const uint8_t* del;        /* deletion gap-open penalties */
+    const uint8_t* gcp;        /* gap continuation penalties */
+    uint64_t n_haps;
+    const uint64_t* hap_off;   /* [n_haps + 1] prefix offsets into hap_bases */
+    const uint8_t* hap_bases;  /* ASCII haplotype bases */
+    uint64_t n_pairs;
+    const uint32_t* pair_read; /* [n_pairs] read index of test case i */
+    const uint32_t* pair_hap;  /* [n_pairs] haplotype index of test case i */
+} mgx_pairhmm_input_t;
+
+typedef struct mgx_pairhmm_stats {
+    uint64_t n_pairs;
+    uint64_t cells;            /* sum of R*H over the batch */
+    uint64_t alg_bytes;        /* sum of 5R + H + 4 */
+    uint64_t n_rerun_f64;      /* test cases whose fp32 result was < 1e-28f (last run) */
+    uint32_t n_launches_f32;   /* kernel launches of the fp32 recurrence per run */
+    uint32_t n_launches_f64;
+    /* valid only with MGX_PAIRHMM_TIMING, for the last mgx_pairhmm_batch_run: */
+    float ms_f32;              /* sum of the fp32 recurrence kernels' durations */
+    float ms_f64;              /* sum of the fp64 re-run kernels' durations */
+    float ms_f32_dominant;     /* duration of the largest fp32 launch ... */
+    uint64_t dominant_cells;   /* ... and the cells / algorithmic bytes it processed */
+    uint64_t dominant_alg_bytes;
+    char dominant_kernel[64];  /* its name as rocprofv3 prints it (prefix) */
+} mgx_pairhmm_stats_t;
+
+const char* mgx_last_error(void);
+
+/* device: HIP device ordinal.  Builds the Context<float>/Context<double> tables
+ * (intel/pairhmm/Context.h) on the host and uploads them. */
+int mgx_pairhmm_create(int device, unsigned flags, mgx_pairhmm_t** out);
+void mgx_pairhmm_destroy(mgx_pairhmm_t* ctx);
+
+/* One shot: host buffers in, log10 likelihoods out (out_log10[i] for test case i). */
+int mgx_pairhmm_compute(mgx_pairhmm_t* ctx, const mgx_pairhmm_input_t* in, double* out_log10);
+
+/* Staged form.  batch_create bins the test cases by shape, stages the packed arrays through
+ * pinned memory and uploads them on the context's copy stream; after it returns the batch is
+ * resident in HBM.  batch_run only enqueues kernels on the compute stream (asynchronous).
+ * batch_results waits for the stream and copies the results back (used_f64 may be NULL). */
+int mgx_pairhmm_batch_create(mgx_pairhmm_t* ctx, const mgx_pairhmm_input_t* in,
+                             mgx_pairhmm_batch_t** out);
+int mgx_pairhmm_batch_run(mgx_pairhmm_t* ctx, mgx_pairhmm_batch_t* batch);
+int mgx_pairhmm_batch_results(mgx_pairhmm_t* ctx, mgx_pairhmm_batch_t* batch, double* out_log10,
+                              uint8_t* used_f64);
+int mgx_pairhmm_batch_stats(mgx_pairhmm_t* ctx, mgx_pairhmm_batch_t* batch,
+                            mgx_pairhmm_stats_t* out);
+void mgx_pairhmm_batch_destroy(mgx_pairhmm_t* ctx, mgx_pairhmm_batch_t* batch);
+int mgx_pairhmm_sync(mgx_pairhmm_t* ctx);
+
+/* The two probability tables as built by the product (for table-parity tests):
+ * which = 0: ph2pr[128]; which = 1: matchToMatchProb[32640].  Returns the element count. */
+int mgx_pairhmm_table_f32(int which, const float** out);
+int mgx_pairhmm_table_f64(int which, const double** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_PAIRHMM_H */
