@@ -1,0 +1,158 @@
+"""Headline benchmark: PairHMM GCUPS on BASELINE.json configs[1] (1M synthetic test cases,
+read 128 x haplotype 256, fp32 with fp64 re-run) per GPU; one process per GPU, no collectives on
+the data path (test cases are independent -> ranks own disjoint shards, "weak" scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the resident batch: the fp32 recurrence kernel over all
+test cases plus the fp64 re-run of those that underflowed, with results left in HBM.  Inputs are
+uploaded before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "fast-genomic-data-processing_amd"
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+
+
+def cpu_baseline(synth, n_sample, seed):
+    """Times the CPU checker on a bounded sample of the same workload, on this box's host cores.
+    kind = "reference": the reference's own AVX kernels (oracle/_ref, prebuilt in the build
+    container); kind = "port": this repo's scalar restatement (oracle/pairhmm_oracle.c)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import PairHMMOracle, _ensure_oracle
+    d = synth.gen_pairhmm_pairs(n_sample, seed)
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_pairhmm.so")
+    if os.path.exists(ref_so):
+        orc, kind, sample_mul = PairHMMOracle(ref_so, "ref_pairhmm_batch"), "reference", 1
+    else:
+        orc, kind, sample_mul = PairHMMOracle(_ensure_oracle()), "port", 8
+        n_sample //= sample_mul
+        d = synth.gen_pairhmm_pairs(n_sample, seed)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    orc.batch(synth.gen_pairhmm_pairs(256, seed), threads=cores)   # warm the tables / threads
+    t0 = time.perf_counter()
+    orc.batch(d, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": d["cells"] / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+            "sample": f"first {n_sample} test cases of the workload (R=128, H=256), "
+                      f"{d['cells'] / 1e9:.2f} Gcells in {dt:.2f} s wall on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=1 << 20, help="test cases per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    seed = 0x5EED0002 + 0x1000 * rank                  # every rank owns its own shard of test cases
+    d = synth.gen_pairhmm_pairs(args.pairs, seed)      # configs[1], sub-run 2a: fixed R=128, H=256
+    eng = pkg.PairHMMEngine(local_rank, flags=pkg.pairhmm.TIMING)
+    t0 = time.perf_counter()
+    batch = eng.batch(d)                               # bins + uploads: resident in HBM from here on
+    upload_s = time.perf_counter() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(local_rank)
+        eng.sync()
+
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    t0 = time.perf_counter()
+    ms_dom = 0.0
+    for _ in range(args.steps):
+        batch.run()
+        # HIP events recorded on the kernel's own stream, read back after the step completes
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = batch.stats()                                  # events of the last step
+    ms_dom = st["ms_f32_dominant"]
+    # average dominant-kernel duration over a few extra (untimed) steps, events read per step
+    durs = []
+    for _ in range(min(args.steps, 10)):
+        batch.run()
+        durs.append(batch.stats()["ms_f32_dominant"])
+    ms_dom = float(np.mean(durs))
+
+    tmax = dt
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+    cells_per_step_all = d["cells"] * world             # every rank holds an equal-size shard
+    value = cells_per_step_all * args.steps / tmax / 1e9
+
+    if rank == 0:
+        alg_bytes = st["dominant_alg_bytes"]
+        achieved = alg_bytes / (ms_dom * 1e-3) / 1e9
+        line = {
+            "metric": "PairHMM GCUPS", "value": value, "unit": "GCUPS", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": tmax / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1], sub-run 2a: 1M synthetic read x haplotype "
+                                   "test cases per GPU, read 128 x hap 256, fp32 + fp64 re-run of results < 1e-28",
+                       "pairs_per_gpu": args.pairs, "read_len": 128, "hap_len": 256, "seed": hex(seed),
+                       "rerun_f64_per_step": st["n_rerun_f64"], "parallelism": f"shard{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": st["dominant_kernel"], "kernel_ms": ms_dom,
+                         "alg_bytes_per_launch": alg_bytes,
+                         "note": "5R+H+4 algorithmic bytes per test case (SURVEY.md 8d); the kernel is "
+                                 "fp32-VALU-issue bound, not HBM bound -- see valu"},
+            "valu": {"achieved": 12.0 * st["dominant_cells"] / (ms_dom * 1e-3) / 1e12,
+                     "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": 12.0 * st["dominant_cells"] / (ms_dom * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                     "kernel_gcups": st["dominant_cells"] / (ms_dom * 1e-3) / 1e9,
+                     "note": "12 flop per cell (SURVEY.md 8d) against the fp32 vector peak"},
+            "upload_s": upload_s,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(synth, 1 << 18, seed)
+        print(json.dumps(line), flush=True)
+    batch.close()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,12 @@ inline void shape_of(uint32_t R, int* G, int* RPL) {
     else if (R <= (uint32_t)kMaxRowsG64) { *G = 64; *RPL = (int)((R + 63) / 64); }
     else { *G = 0; *RPL = 0; }
 }
+// dynamic LDS of one block: per-wavefront emission table (fp32 only) + per-group haplotype codes
+inline uint32_t lds_bytes(const Bin& bin, bool f32) {
+    const uint32_t waves = bin.block / 64u, groups = bin.block / (uint32_t)bin.G;
+    const uint32_t etab = f32 ? (uint32_t)((bin.RPL + 1) / 2) * kNumCodes * 512u : 0u;
+    return waves * etab + groups * bin.lds_stride;
+}
 inline int bin_index(int G, int RPL) { return (G == 16 ? 0 : 8) + RPL - 1; }
 
 int validate(const mgx_pairhmm_input_t* in) {
@@ -251,10 +257,11 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
                 bin.cells += (uint64_t)jobs[q].R * jobs[q].H;
                 bin.alg_bytes += 5ull * jobs[q].R + jobs[q].H + 4;
             }
-            bin.lds_stride = (bin.max_h + 2 + 15) & ~15u;
-            bin.block = 256;
-            while (bin.block > (uint32_t)bin.G && (bin.block / bin.G) * bin.lds_stride > kMaxLdsPerBlock) bin.block /= 2;
-            if ((bin.block / bin.G) * bin.lds_stride > 160u * 1024u) {
+            // LDS per group: G pad + codes + G pad + prefetch slack (see the kernel's staging loop)
+            bin.lds_stride = (bin.max_h + 2u * (uint32_t)bin.G + 8u + 15u) & ~15u;
+            bin.block = 128;                  // 2 wavefronts: fine-grained LDS/VGPR packing per CU
+            while (bin.block > 64u && lds_bytes(bin, true) > kMaxLdsPerBlock) bin.block /= 2;
+            if (lds_bytes(bin, true) > 160u * 1024u) {
                 set_error("haplotype of %u bases does not fit the LDS staging buffer", bin.max_h);
                 return -E2BIG;
             }
@@ -310,14 +317,13 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         a.lds_stride = bin.lds_stride;
         a.log10_initial_f = c->log10_initial_f;
         a.log10_initial_d = c->log10_initial_d;
-        const uint32_t lds = (bin.block / bin.G) * bin.lds_stride;
         if (!force_f64) {
             a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count;
             a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f;
             KernelFn f = pick_kernel<float>(bin.G, bin.RPL);
             if (!f) { set_error("no fp32 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 0], s));
-            hipLaunchKernelGGL(f, dim3(bin.grid_f32), dim3(bin.block), lds, s, a);
+            hipLaunchKernelGGL(f, dim3(bin.grid_f32), dim3(bin.block), lds_bytes(bin, true), s, a);
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 1], s));
         }
         {
@@ -327,7 +333,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             KernelFn f = pick_kernel<double>(bin.G, bin.RPL);
             if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 2], s));
-            hipLaunchKernelGGL(f, dim3(force_f64 ? bin.grid_f32 : bin.grid_f64), dim3(bin.block), lds, s, a);
+            hipLaunchKernelGGL(f, dim3(force_f64 ? bin.grid_f32 : bin.grid_f64), dim3(bin.block), lds_bytes(bin, false), s, a);
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 3], s));
         }
     }

@@ -1,0 +1,111 @@
+"""GPU parity tests of the PairHMM path (run with -m gpu): the HIP kernels, called through the
+C ABI, against the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+
+from test_pairhmm_oracle import KEYS, TOL, assert_log10_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def run(engine, d, flags=False):
+    b = engine.batch(d)
+    b.run()
+    res = b.results(with_flags=True)
+    st = b.stats()
+    b.close()
+    return res[0], res[1], st
+
+
+@pytest.mark.parametrize("name", ["pairhmm_cfg1.npz", "pairhmm_edge.npz"])
+def test_golden_vectors(engine, name):
+    g = load_golden(name)
+    out, used, _ = run(engine, g)
+    assert_log10_close(out, g["expected"])
+    # same float-first / double-fallback decision as the reference, except within an ulp of 1e-28f
+    assert (used != g["used_f64"]).sum() <= 1
+
+
+def test_one_shot_compute_matches_staged(engine):
+    g = load_golden("pairhmm_cfg1.npz")
+    a = engine.compute(g)
+    b, _, _ = run(engine, g)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("r_range,h_range,n", [((1, 128), (1, 256), 20000), ((100, 128), (200, 256), 8000),
+                                                ((129, 512), (10, 600), 1500), ((1, 16), (1, 40), 5000)])
+def test_random_ragged_vs_oracle(engine, oracle, synth, r_range, h_range, n):
+    d = synth.gen_pairhmm_pairs(n, 0x5EED0002 ^ n, r_range=r_range, h_range=h_range, hap_n_rate=0.01)
+    want, wused = oracle.batch(d)
+    out, used, st = run(engine, d)
+    assert_log10_close(out, want)
+    assert (used != wused).sum() <= max(2, n // 2000)
+    assert st["cells"] == d["cells"] and st["alg_bytes"] == d["alg_bytes"]
+    assert st["n_rerun_f64"] == int(used.sum())
+
+
+def test_region_all_pairs_with_duplicate_reads(engine, oracle, synth):
+    d = synth.gen_pairhmm_region(96, 128, 77, r_range=(60, 128), h_range=(180, 256), dup_reads=8)
+    want, _ = oracle.batch(d)
+    out, _, _ = run(engine, d)
+    assert_log10_close(out, want)
+
+
+def test_force_double_matches_fp64_oracle(pkg, oracle, synth):
+    """PairHMMNativeArgumentCollection.useDoublePrecision: every test case through the fp64 kernel."""
+    import ctypes
+    import os
+    from conftest import ROOT
+    d = synth.gen_pairhmm_pairs(4000, 99, r_range=(1, 128), h_range=(1, 256))
+    eng = pkg.PairHMMEngine(0, flags=pkg.pairhmm.FORCE_DOUBLE)
+    out, used, _ = run(eng, d)
+    eng.close()
+    assert used.all()
+    olib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libpairhmm_oracle.so"))
+    olib.ph_oracle_init()
+    olib.ph_oracle_prob_f64.restype = ctypes.c_double
+    ro, ho = d["read_off"].astype(np.int64), d["hap_off"].astype(np.int64)
+    P = lambda a, o: ctypes.c_void_p(a.ctypes.data + int(o))  # noqa: E731
+    log10_init = np.log10(np.ldexp(1.0, 1020))
+    for i in range(0, 4000, 7):
+        R, H = int(ro[i + 1] - ro[i]), int(ho[i + 1] - ho[i])
+        v = olib.ph_oracle_prob_f64(R, P(d["bases"], ro[i]), P(d["qual"], ro[i]), P(d["ins"], ro[i]),
+                                    P(d["dele"], ro[i]), P(d["gcp"], ro[i]), H, P(d["hap_bases"], ho[i]))
+        assert abs(out[i] - (np.log10(v) - log10_init)) < 1e-9
+
+
+def test_full_size_properties(engine, oracle, synth):
+    """BASELINE.json configs[1] at full size (1M test cases, R=128, H=256): a sampled oracle check
+    plus size-independent properties -- order invariance and determinism."""
+    n = 1 << 20
+    d = synth.gen_pairhmm_pairs(n, 0x5EED0002)
+    out, used, st = run(engine, d)
+    assert st["cells"] == n * 128 * 256
+    assert not np.isnan(out).any() and (out < 0).all()
+    # every 4096th test case against the oracle
+    idx = np.arange(0, n, 4096)
+    sub = dict(d)
+    sub["pair_read"], sub["pair_hap"] = d["pair_read"][idx], d["pair_hap"][idx]
+    want, _ = oracle.batch(sub)
+    assert_log10_close(out[idx], want)
+    # permuting the test-case list permutes the results bit for bit
+    perm = np.random.RandomState(5).permutation(n)
+    dp = dict(d)
+    dp["pair_read"], dp["pair_hap"] = d["pair_read"][perm], d["pair_hap"][perm]
+    outp, usedp, _ = run(engine, dp)
+    assert np.array_equal(outp, out[perm]) and np.array_equal(usedp, used[perm])
+
+
+def test_read_longer_than_supported_is_an_error_not_a_fallback(pkg, engine, synth):
+    d = synth.gen_pairhmm_pairs(4, 3, r_range=(513, 513), h_range=(600, 600))
+    with pytest.raises(pkg.MgxError, match="row limit"):
+        engine.compute(d)
+
+
+def test_empty_batch(engine):
+    g = load_golden("pairhmm_cfg1.npz")
+    e = dict(g)
+    e["pair_read"] = np.zeros(0, dtype=np.uint32)
+    e["pair_hap"] = np.zeros(0, dtype=np.uint32)
+    assert engine.compute(e).shape == (0,)

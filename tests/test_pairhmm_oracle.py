@@ -1,0 +1,112 @@
+"""CPU-side checks (run with -m "not gpu"): the oracle against the reference's golden vectors and
+against the reference build itself, the product's probability tables, and the C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+KEYS = ("read_off", "bases", "qual", "ins", "dele", "gcp", "hap_off", "hap_bases", "pair_read", "pair_hap")
+# the reference's own fp32-vs-fp64 spread is 3e-6; north_star asks for 1e-5 abs
+TOL = 1e-5
+
+
+def load_golden(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", name))
+    return {k: z[k] for k in z.files}
+
+
+def assert_log10_close(got, want, tol=TOL):
+    got, want = np.asarray(got), np.asarray(want)
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf)
+    assert np.array_equal(got[inf], want[inf])
+    assert not np.isnan(got).any()
+    err = np.abs(got[~inf] - want[~inf])
+    assert err.max(initial=0.0) <= tol, f"max abs err {err.max()} at {np.argmax(err)}"
+
+
+@pytest.mark.parametrize("name", ["pairhmm_cfg1.npz", "pairhmm_edge.npz"])
+def test_oracle_matches_reference_golden(oracle, name):
+    g = load_golden(name)
+    out, used = oracle.batch(g, threads=1)
+    assert_log10_close(out, g["expected"])
+    # the fp64 branch of the reference (result < 1e-28f) is bit-exact with the restatement to ~1e-13
+    both = (used == 1) & (g["used_f64"] == 1) & ~np.isinf(g["expected"])
+    assert np.abs(out[both] - g["expected"][both]).max(initial=0.0) < 1e-9
+
+
+def test_oracle_matches_reference_build_live(oracle, ref_oracle, synth):
+    d = synth.gen_pairhmm_pairs(3000, 0x5EED0002, r_range=(1, 128), h_range=(1, 256))
+    a, ua = oracle.batch(d)
+    b, ub = ref_oracle.batch(d)
+    assert_log10_close(a, b)
+    assert (ua != ub).sum() <= 3      # only results within an ulp of 1e-28f may flip branch
+
+
+def test_product_tables_equal_oracle_tables(pkg):
+    """mgx_tables.cpp (product) against oracle/pairhmm_oracle.c (restatement of Context.h)."""
+    lib = pkg.native.load()
+    olib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libpairhmm_oracle.so"))
+    for which, fn32, fn64, n in ((0, "ph_oracle_table_ph2pr_f32", "ph_oracle_table_ph2pr_f64", 128),
+                                 (1, "ph_oracle_table_mm_f32", "ph_oracle_table_mm_f64", 32640)):
+        p = ctypes.c_void_p()
+        assert lib.mgx_pairhmm_table_f32(which, ctypes.byref(p)) == n
+        mine = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), (n,))
+        getattr(olib, fn32).restype = ctypes.POINTER(ctypes.c_float)
+        want = np.ctypeslib.as_array(getattr(olib, fn32)(), (n,))
+        assert np.array_equal(mine.view(np.uint32), want.view(np.uint32))
+        assert lib.mgx_pairhmm_table_f64(which, ctypes.byref(p)) == n
+        mine = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), (n,))
+        getattr(olib, fn64).restype = ctypes.POINTER(ctypes.c_double)
+        want = np.ctypeslib.as_array(getattr(olib, fn64)(), (n,))
+        assert np.array_equal(mine.view(np.uint64), want.view(np.uint64))
+
+
+def test_known_answer_from_survey(oracle):
+    """a 32-base exact-match read in a 57-base haplotype gives
+    -1.816371918 through the reference (initNative(false,1) + computeLikelihoodsNative_concurrent_i)
+    with Q30 bases, Q40 gap-open, Q10 gap-continuation; edge case 4 of the fixture is that shape."""
+    g = load_golden("pairhmm_edge.npz")
+    out, _ = oracle.batch(g, threads=1)
+    assert abs(g["expected"][4] - out[4]) < TOL
+
+
+def _declared_functions(header):
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_cabi_exports_every_declared_symbol(pkg):
+    lib = pkg.native.load()
+    inc = os.path.join(ROOT, "include")
+    declared = []
+    for h in sorted(os.listdir(inc)):
+        declared += _declared_functions(os.path.join(inc, h))
+    assert "mgx_pairhmm_compute" in declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported by libmgx.so"
+        assert name in pkg.native.SYMBOLS, f"{name} has no ctypes prototype in native.py"
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a HIP device the product must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.MgxError, match="no HIP device"):
+        pkg.PairHMMEngine(0)
+
+
+def test_product_does_not_reference_oracle():
+    """Nothing under the package may import, link or dlopen anything under oracle/."""
+    pkgdir = os.path.join(ROOT, "fast-genomic-data-processing_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".inc", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in txt and "ph_oracle" not in txt and "libpairhmm_oracle" not in txt, f
