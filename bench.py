@@ -27,6 +27,32 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return t.get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(synth, n_sample, seed):
     """Times the CPU checker on a bounded sample of the same workload, on this box's host cores.
     kind = "reference": the reference's own AVX kernels (oracle/_ref, prebuilt in the build
@@ -41,11 +67,7 @@ def cpu_baseline(synth, n_sample, seed):
         orc, kind, sample_mul = PairHMMOracle(_ensure_oracle()), "port", 8
         n_sample //= sample_mul
         d = synth.gen_pairhmm_pairs(n_sample, seed)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     orc.batch(synth.gen_pairhmm_pairs(256, seed), threads=cores)   # warm the tables / threads
     t0 = time.perf_counter()
     orc.batch(d, threads=cores)
@@ -132,7 +154,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "read_len": 128, "hap_len": 256, "seed": hex(seed),
                        "rerun_f64_per_step": st["n_rerun_f64"], "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(st["dominant_kernel"]),
                          "kernel": st["dominant_kernel"], "kernel_ms": ms_dom,
                          "alg_bytes_per_launch": alg_bytes,
                          "note": "5R+H+4 algorithmic bytes per test case (SURVEY.md 8d); the kernel is "
