@@ -7,3 +7,5 @@ been built, or no HIP device is visible, every entry point raises.
 from . import native  # noqa: F401
 from .native import MgxError, lib_path, load  # noqa: F401
 from .pairhmm import PairHMMEngine, PairHMMBatch  # noqa: F401
+from .sortdedup import SortDedupEngine  # noqa: F401
+from . import pairhmm, sortdedup, synth  # noqa: F401

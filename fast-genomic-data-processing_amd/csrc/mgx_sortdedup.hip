@@ -1,0 +1,765 @@
+// mgx_sortdedup.hip -- device half of the sort / mark-duplicate path for MI355X (gfx950).
+//
+// Re-expresses sortmardup/main.cpp:235-388 (three per-partition std::sort/std::stable_sort calls,
+// two run scans, two bitmaps) as an HBM-bound pipeline over packed 32-byte records:
+//
+//   build      records -> coordinate keys, compacted double-pair / single-pair entries
+//              (pair.cpp:51-108 key rules) + indicator bits (main.cpp:181-192) + key maxima
+//   radix      stable LSD radix sort, 8-bit digits, 4096-key tiles: per-tile histogram ->
+//              column-wise scan -> ranked scatter through LDS (used for: doubles by mate 5' end,
+//              doubles by sort_key, singles by sort_key, records by unified coordinate)
+//   best-of-run  every run of equal keys keeps its best entry (score desc, tile/x/y asc, arrival
+//              asc), the rest are duplicates (main.cpp:269-280, 319-340); singles additionally
+//              test the indicator bitmap
+//
+// No collective and no host round trip inside the pipeline except one 64-byte read-back of the
+// entry counts and key maxima (they size the sorts and pick the number of digit passes).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "../../include/mgx_sortdedup.h"
+#include "mgx_common.h"
+
+using mgx::set_error;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                      __LINE__);                                                           \
+            return -EIO;                                                                   \
+        }                                                                                  \
+    } while (0)
+
+using u64 = unsigned long long;   // == uint64_t on this ABI; the type HIP atomics are declared for
+using u32 = uint32_t;
+
+constexpr int kTileThreads = 256;
+constexpr int kItems = 16;
+constexpr int kTile = kTileThreads * kItems;          // 4096 keys per workgroup
+constexpr int kChunkTiles = 128;                      // tiles per column-scan chunk
+constexpr u32 kIgnorable = 0x4 | 0x100 | 0x800;
+constexpr int kWalkCap = 64;                          // longest run a single lane walks
+
+struct Scalars {            // device-side scalars, one 64-byte read-back
+    u64 max_coord, max_k1d, max_k2d, max_k1s;
+    u32 n_double, n_single, n_long_d, n_long_s;
+    u32 n_dup, pad_[3];
+};
+
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// exclusive scan of one u32 per thread over a 256-thread block (4 wavefronts); returns the
+// exclusive prefix, *total gets the block sum.  sm must hold 4 u32.
+__device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* sm, u32* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) sm[wave] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const u32 s = sm[w]; if (w < wave) base += s; tot += s; }
+    *total = tot;
+    return base + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// build: classify records, count entries per 1024-record block
+// ---------------------------------------------------------------------------------------------
+constexpr int kBuildBlock = 1024;
+
+__device__ __forceinline__ int classify(const mgx_rec_t& r, u32 i) {
+    // 0 = no entry, 1 = record 1 of a double pair, 2 = single pair
+    if (r.flag & kIgnorable) return 0;
+    if (r.mate == MGX_NO_MATE) return 2;
+    return r.mate > i ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_build_count(const mgx_rec_t* recs, u32 n, u32* blk_d, u32* blk_s) {
+    __shared__ u32 sm[8];
+    const u32 base = blockIdx.x * kBuildBlock;
+    u32 cd = 0, cs = 0;
+    for (int k = 0; k < kBuildBlock / 256; ++k) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            const int c = classify(recs[i], i);
+            cd += c == 1; cs += c == 2;
+        }
+    }
+    u32 td, ts;
+    block_excl_scan_256(cd, sm, &td);
+    block_excl_scan_256(cs, sm + 4, &ts);
+    if (threadIdx.x == 0) { blk_d[blockIdx.x] = td; blk_s[blockIdx.x] = ts; }
+}
+
+// single-block exclusive scan of up to a few million u32 (block counts), in place; totals out
+__global__ __launch_bounds__(1024) void k_scan_counts(u32* a, u32* b, u32 n, Scalars* sc) {
+    __shared__ u32 part[2][1024];
+    const u32 per = (n + 1023) / 1024;
+    const u32 lo = threadIdx.x * per, hi = min(n, lo + per);
+    u32 sa = 0, sb = 0;
+    for (u32 i = lo; i < hi; ++i) { sa += a[i]; sb += b[i]; }
+    part[0][threadIdx.x] = sa; part[1][threadIdx.x] = sb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 ra = 0, rb = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const u32 xa = part[0][t], xb = part[1][t];
+            part[0][t] = ra; part[1][t] = rb; ra += xa; rb += xb;
+        }
+        sc->n_double = ra; sc->n_single = rb;
+    }
+    __syncthreads();
+    u32 ra = part[0][threadIdx.x], rb = part[1][threadIdx.x];
+    for (u32 i = lo; i < hi; ++i) { const u32 xa = a[i], xb = b[i]; a[i] = ra; b[i] = rb; ra += xa; rb += xb; }
+}
+
+struct BuildOut {
+    u64* ckey; u32* cval;                 // coordinate sort input
+    u64* dk1; u64* dk2; u32* drec;        // double-pair entries (compacted, arrival order)
+    u64* sk1; u32* srec;                  // single-pair entries
+    u32* indicator; u64 indicator_bits;   // double_pair_indicator, 4L bits
+    u64 L;
+};
+
+__global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n, const u32* blk_d, const u32* blk_s,
+                                                    BuildOut o, Scalars* sc) {
+    __shared__ u32 sm[8];
+    __shared__ u64 smax[4][4];
+    const u32 base = blockIdx.x * kBuildBlock;
+    u32 run_d = blk_d[blockIdx.x], run_s = blk_s[blockIdx.x];
+    u64 m_coord = 0, m_k1d = 0, m_k2d = 0, m_k1s = 0;
+    for (int k = 0; k < kBuildBlock / 256; ++k) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        int c = 0;
+        mgx_rec_t r;
+        if (i < n) {
+            r = recs[i];
+            c = classify(r, i);
+            o.ckey[i] = r.coord; o.cval[i] = i;
+            m_coord = max(m_coord, (u64)r.coord);
+        }
+        u32 td, ts;
+        const u32 pd = block_excl_scan_256(c == 1, sm, &td);
+        const u32 ps = block_excl_scan_256(c == 2, sm + 4, &ts);
+        if (c == 1) {
+            // DoublePair::DoublePair, pair.cpp:71-108
+            const mgx_rec_t m = recs[r.mate];
+            u64 p1 = r.prime5, p2 = m.prime5;
+            bool f1 = !(r.flag & 0x10), f2 = !(m.flag & 0x10);
+            if (p1 > p2) { const u64 t = p1; p1 = p2; p2 = t; const bool tf = f1; f1 = f2; f2 = tf; }
+            u32 orient = f1 ? (f2 ? 0u : 1u) : (f2 ? 2u : 3u);       // FF FR RF RR
+            if (p1 == p2 && orient == 2u) orient = 1u;
+            const u64 k1 = (p1 << 2) + orient;
+            const u32 at = run_d + pd;
+            o.dk1[at] = k1; o.dk2[at] = p2; o.drec[at] = i;
+            m_k1d = max(m_k1d, k1); m_k2d = max(m_k2d, p2);
+            // main.cpp:181-192
+            const u64 b2 = p2 + ((orient == 0u || orient == 2u) ? 0ull : o.L);
+            const u64 b1 = p1 + ((orient == 0u || orient == 1u) ? 0ull : o.L);
+            if (b2 < o.indicator_bits) atomicOr(&o.indicator[b2 >> 5], 1u << (b2 & 31));
+            if (b1 < o.indicator_bits) atomicOr(&o.indicator[b1 >> 5], 1u << (b1 & 31));
+        } else if (c == 2) {
+            // SinglePair::SinglePair, pair.cpp:51-69
+            const u64 k1 = (r.prime5 << 2) + ((r.flag & 0x10) ? 3u : 0u);
+            const u32 at = run_s + ps;
+            o.sk1[at] = k1; o.srec[at] = i;
+            m_k1s = max(m_k1s, k1);
+        }
+        run_d += td; run_s += ts;
+    }
+    // block max -> 4 global atomics
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m_coord = max(m_coord, (u64)__shfl_xor(m_coord, off, 64));
+        m_k1d = max(m_k1d, (u64)__shfl_xor(m_k1d, off, 64));
+        m_k2d = max(m_k2d, (u64)__shfl_xor(m_k2d, off, 64));
+        m_k1s = max(m_k1s, (u64)__shfl_xor(m_k1s, off, 64));
+    }
+    if (lane == 0) { smax[wave][0] = m_coord; smax[wave][1] = m_k1d; smax[wave][2] = m_k2d; smax[wave][3] = m_k1s; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const u64 v = max(max(smax[0][threadIdx.x], smax[1][threadIdx.x]), max(smax[2][threadIdx.x], smax[3][threadIdx.x]));
+        u64* dst = threadIdx.x == 0 ? &sc->max_coord : threadIdx.x == 1 ? &sc->max_k1d : threadIdx.x == 2 ? &sc->max_k2d : &sc->max_k1s;
+        atomicMax(dst, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// radix sort pass: histogram -> column scan -> ranked scatter
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_radix_hist(const u64* __restrict__ keys, u32 n, int shift, u32* __restrict__ hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 base = blockIdx.x * kTile;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];     // tile-major: coalesced
+}
+
+// column sums per chunk of kChunkTiles tiles
+__global__ __launch_bounds__(256) void k_radix_chunk_sums(const u32* __restrict__ hist, u32 n_tiles, u32* __restrict__ chunk_sums) {
+    const u32 t0 = blockIdx.x * kChunkTiles, t1 = min(n_tiles, t0 + kChunkTiles);
+    u32 s = 0;
+    for (u32 t = t0; t < t1; ++t) s += hist[(size_t)t * 256 + threadIdx.x];
+    chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// one block: digit bases (exclusive over digits) + exclusive scan over chunks per digit column
+__global__ __launch_bounds__(256) void k_radix_scan_chunks(u32* chunk_sums, u32 n_chunks) {
+    __shared__ u32 sm[4];
+    u32 tot = 0;
+    for (u32 c = 0; c < n_chunks; ++c) tot += chunk_sums[(size_t)c * 256 + threadIdx.x];
+    u32 all;
+    u32 run = block_excl_scan_256(tot, sm, &all);      // where this digit starts in the output
+    for (u32 c = 0; c < n_chunks; ++c) {
+        const u32 x = chunk_sums[(size_t)c * 256 + threadIdx.x];
+        chunk_sums[(size_t)c * 256 + threadIdx.x] = run;
+        run += x;
+    }
+}
+
+// per chunk: running prefix down the tiles of the chunk, in place: hist[tile][d] -> global offset
+__global__ __launch_bounds__(256) void k_radix_apply(u32* __restrict__ hist, u32 n_tiles, const u32* __restrict__ chunk_sums) {
+    const u32 t0 = blockIdx.x * kChunkTiles, t1 = min(n_tiles, t0 + kChunkTiles);
+    u32 run = chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x];
+    for (u32 t = t0; t < t1; ++t) {
+        const u32 x = hist[(size_t)t * 256 + threadIdx.x];
+        hist[(size_t)t * 256 + threadIdx.x] = run;
+        run += x;
+    }
+}
+
+template <bool HAS_P64>
+__global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ kin, u64* __restrict__ kout,
+                                                       const u64* __restrict__ pin64, u64* __restrict__ pout64,
+                                                       const u32* __restrict__ pin32, u32* __restrict__ pout32,
+                                                       u32 n, int shift, const u32* __restrict__ goff) {
+    __shared__ u64 sbuf[kTile];             // 32 KB exchange buffer (keys, then payloads)
+    __shared__ u32 wcnt[4][256];
+    __shared__ u32 tile_base[256];
+    __shared__ u32 gbase[256];
+    __shared__ u32 sm[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tile0 = blockIdx.x * kTile;
+    const u32 tile_n = min((u32)kTile, n - tile0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+    gbase[tid] = goff[(size_t)blockIdx.x * 256 + tid];
+    __syncthreads();
+
+    // phase 1: stable rank of every key inside its wavefront's 1024-key slice
+    u64 key[kItems];
+    u32 lrank[kItems];
+    const u64 lt = lanemask_lt();
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const u32 li = wave * (kTile / 4) + k * 64 + lane;      // local index: slices are contiguous per wave
+        const bool valid = li < tile_n;
+        key[k] = valid ? kin[tile0 + li] : ~0ull;
+        const u32 d = (u32)(key[k] >> shift) & 255u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const u32 r = __popcll(peers & lt);
+        u32 old = 0;
+        if (valid && r == 0) old = atomicAdd(&wcnt[wave][d], (u32)__popcll(peers));
+        const int leader = __ffsll((long long)peers) - 1;
+        old = __shfl(old, leader < 0 ? 0 : leader, 64);
+        lrank[k] = old + r;
+    }
+    __syncthreads();
+    // phase 2: per digit, exclusive over the 4 wavefronts, then exclusive over digits
+    {
+        u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+        wcnt[0][tid] = 0; wcnt[1][tid] = c0; wcnt[2][tid] = c0 + c1; wcnt[3][tid] = c0 + c1 + c2;
+        u32 all;
+        tile_base[tid] = block_excl_scan_256(c0 + c1 + c2 + c3, sm, &all);
+    }
+    __syncthreads();
+    // phase 3: keys to their tile-local sorted slot, then out in runs of consecutive addresses
+    u32 lpos[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const u32 li = wave * (kTile / 4) + k * 64 + lane;
+        const u32 d = (u32)(key[k] >> shift) & 255u;
+        lpos[k] = tile_base[d] + wcnt[wave][d] + lrank[k];
+        if (li < tile_n) sbuf[lpos[k]] = key[k];
+    }
+    __syncthreads();
+    u32 gpos[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const u32 i = k * 256 + tid;
+        gpos[k] = 0;
+        if (i < tile_n) {
+            const u64 kk = sbuf[i];
+            const u32 d = (u32)(kk >> shift) & 255u;
+            gpos[k] = gbase[d] + (i - tile_base[d]);
+            kout[gpos[k]] = kk;
+        }
+    }
+    if constexpr (HAS_P64) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const u32 li = wave * (kTile / 4) + k * 64 + lane;
+            if (li < tile_n) sbuf[lpos[k]] = pin64[tile0 + li];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const u32 i = k * 256 + tid;
+            if (i < tile_n) pout64[gpos[k]] = sbuf[i];
+        }
+    }
+    __syncthreads();
+    u32* sbuf32 = reinterpret_cast<u32*>(sbuf);
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const u32 li = wave * (kTile / 4) + k * 64 + lane;
+        if (li < tile_n) sbuf32[lpos[k]] = pin32[tile0 + li];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const u32 i = k * 256 + tid;
+        if (i < tile_n) pout32[gpos[k]] = sbuf32[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// best-of-run and duplicate marking
+// ---------------------------------------------------------------------------------------------
+// quality of a pair entry: smaller is better -- score descending, then tile, x, y ascending
+// (main.cpp:253-264 / 303-314); sorted position breaks total ties (= arrival order, LSD is stable)
+__device__ __forceinline__ u64 quality_double(const mgx_rec_t* recs, u32 rec) {
+    const mgx_rec_t a = recs[rec];
+    const mgx_rec_t b = recs[a.mate];
+    const u32 score = (u32)(uint16_t)(a.score + b.score);                // pair.cpp:81
+    return ((u64)(0xFFFFu - score) << 48) | ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y;
+}
+__device__ __forceinline__ u64 quality_single(const mgx_rec_t* recs, u32 rec) {
+    const mgx_rec_t a = recs[rec];
+    return ((u64)(0xFFFFu - (u32)a.score) << 48) | ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y;
+}
+
+// One lane per run head walks its run (runs are short); runs longer than kWalkCap go to a list
+// that k_mark_long handles with a whole workgroup each.
+template <bool DOUBLE>
+__global__ __launch_bounds__(256) void k_mark_runs(const u64* __restrict__ k1, const u64* __restrict__ k2,
+                                                   const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
+                                                   const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
+                                                   uint8_t* __restrict__ dup, u32* __restrict__ long_list, u32* n_long) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 a1 = k1[i], a2 = DOUBLE ? k2[i] : 0;
+    if (i > 0 && k1[i - 1] == a1 && (!DOUBLE || k2[i - 1] == a2)) return;      // not a run head
+    u32 best = i;
+    u64 bq = DOUBLE ? quality_double(recs, rec[i]) : quality_single(recs, rec[i]);
+    u32 j = i + 1;
+    for (; j < n && j - i < kWalkCap; ++j) {
+        if (k1[j] != a1 || (DOUBLE && k2[j] != a2)) break;
+        const u64 q = DOUBLE ? quality_double(recs, rec[j]) : quality_single(recs, rec[j]);
+        if (q < bq) { bq = q; best = j; }
+    }
+    if (j < n && j - i >= kWalkCap && k1[j] == a1 && (!DOUBLE || k2[j] == a2)) {
+        long_list[atomicAdd(n_long, 1u)] = i;                                     // long run: defer
+        return;
+    }
+    if (!DOUBLE) {
+        // main.cpp:325-331: the kept single is a duplicate iff a double pair has an end there
+        u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
+        if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[rec[best]] = 1;
+    }
+    for (u32 t = i; t < j; ++t) {
+        if (t == best) continue;
+        const u32 r = rec[t];
+        dup[r] = 1;
+        if (DOUBLE) dup[recs[r].mate] = 1;
+    }
+}
+
+template <bool DOUBLE>
+__global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, const u64* __restrict__ k2,
+                                                   const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
+                                                   const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
+                                                   uint8_t* __restrict__ dup, const u32* __restrict__ long_list, const u32* n_long) {
+    __shared__ u64 sq[256];
+    __shared__ u32 sp[256];
+    __shared__ u32 s_end;
+    for (u32 li = blockIdx.x; li < *n_long; li += gridDim.x) {
+        const u32 i = long_list[li];
+        const u64 a1 = k1[i], a2 = DOUBLE ? k2[i] : 0;
+        // pass 1: extent of the run and its best entry
+        u64 bq = ~0ull; u32 bp = 0xFFFFFFFFu;
+        u32 end = n;
+        for (u32 c = i; c < n; c += 256) {
+            const u32 t = c + threadIdx.x;
+            const bool in = t < n && k1[t] == a1 && (!DOUBLE || k2[t] == a2);
+            if (threadIdx.x == 0) s_end = n;
+            __syncthreads();
+            if (t < n && !in) atomicMin(&s_end, t);
+            __syncthreads();
+            const u32 e = s_end;
+            if (t < e) {
+                const u64 q = DOUBLE ? quality_double(recs, rec[t]) : quality_single(recs, rec[t]);
+                if (q < bq || (q == bq && t < bp)) { bq = q; bp = t; }
+            }
+            __syncthreads();
+            if (e < n) { end = e; break; }
+        }
+        sq[threadIdx.x] = bq; sp[threadIdx.x] = bp;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                const u64 q = sq[threadIdx.x + s]; const u32 p = sp[threadIdx.x + s];
+                if (q < sq[threadIdx.x] || (q == sq[threadIdx.x] && p < sp[threadIdx.x])) { sq[threadIdx.x] = q; sp[threadIdx.x] = p; }
+            }
+            __syncthreads();
+        }
+        const u32 best = sp[0];
+        __syncthreads();
+        if (!DOUBLE && threadIdx.x == 0) {
+            u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
+            if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[rec[best]] = 1;
+        }
+        for (u32 t = i + threadIdx.x; t < end; t += 256) {
+            if (t == best) continue;
+            const u32 r = rec[t];
+            dup[r] = 1;
+            if (DOUBLE) dup[recs[r].mate] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_dup(const uint8_t* dup, u32 n, Scalars* sc) {
+    u32 c = 0;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += dup[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&sc->n_dup, c);
+}
+
+inline int bits_of(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b ? b : 1; }
+
+}  // namespace
+
+struct mgx_sortdedup {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t compute = nullptr, copy = nullptr;
+    int n_cu = 256;
+    uint64_t L = 0;
+    u32 n = 0;
+    size_t cap = 0;                        // record capacity of the buffers below
+    mgx_rec_t* d_recs = nullptr;
+    u64 *d_ckey[2] = {nullptr, nullptr}; u32* d_cval[2] = {nullptr, nullptr};
+    u64 *d_k1[2] = {nullptr, nullptr}, *d_k2[2] = {nullptr, nullptr}; u32* d_prec[2] = {nullptr, nullptr};
+    u64* d_sk1[2] = {nullptr, nullptr}; u32* d_srec[2] = {nullptr, nullptr};
+    u32 *d_blk_d = nullptr, *d_blk_s = nullptr, *d_hist = nullptr, *d_chunk = nullptr, *d_long = nullptr;
+    u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
+    uint8_t* d_dup = nullptr;
+    Scalars* d_sc = nullptr;
+    void* pinned[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> ev_scatter;    // pairs (start, stop) per scatter launch
+    size_t ev_used = 0;
+    uint64_t scatter_bytes = 0;
+    int order_buf = 0;                     // which d_cval holds the final order
+    bool ran = false;
+    Scalars sc{};
+    mgx_sortdedup_stats_t stats{};
+};
+
+namespace {
+
+constexpr size_t kPinnedChunk = 64u << 20;
+
+void free_buffers(mgx_sortdedup* c) {
+    (void)hipFree(c->d_recs); c->d_recs = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(c->d_ckey[i]); (void)hipFree(c->d_cval[i]); (void)hipFree(c->d_k1[i]); (void)hipFree(c->d_k2[i]);
+        (void)hipFree(c->d_prec[i]); (void)hipFree(c->d_sk1[i]); (void)hipFree(c->d_srec[i]);
+        c->d_ckey[i] = c->d_k1[i] = c->d_k2[i] = c->d_sk1[i] = nullptr;
+        c->d_cval[i] = c->d_prec[i] = c->d_srec[i] = nullptr;
+    }
+    (void)hipFree(c->d_blk_d); (void)hipFree(c->d_blk_s); (void)hipFree(c->d_hist); (void)hipFree(c->d_chunk);
+    (void)hipFree(c->d_long); (void)hipFree(c->d_dup);
+    c->d_blk_d = c->d_blk_s = c->d_hist = c->d_chunk = c->d_long = nullptr; c->d_dup = nullptr;
+    c->cap = 0;
+}
+
+template <typename T>
+int dalloc(T** p, size_t count) {
+    HIP_TRY(hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return 0;
+}
+
+int ensure_capacity(mgx_sortdedup* c, size_t n) {
+    if (n <= c->cap) return 0;
+    free_buffers(c);
+    int rc = 0;
+    const size_t half = n / 2 + 1;
+    const size_t n_tiles = (n + kTile - 1) / kTile + 1;
+    rc |= dalloc(&c->d_recs, n);
+    for (int i = 0; i < 2 && !rc; ++i) {
+        rc |= dalloc(&c->d_ckey[i], n); rc |= dalloc(&c->d_cval[i], n);
+        rc |= dalloc(&c->d_k1[i], half); rc |= dalloc(&c->d_k2[i], half); rc |= dalloc(&c->d_prec[i], half);
+        rc |= dalloc(&c->d_sk1[i], n); rc |= dalloc(&c->d_srec[i], n);
+    }
+    const size_t n_blocks = (n + kBuildBlock - 1) / kBuildBlock + 1;
+    rc |= dalloc(&c->d_blk_d, n_blocks); rc |= dalloc(&c->d_blk_s, n_blocks);
+    rc |= dalloc(&c->d_hist, n_tiles * 256);
+    rc |= dalloc(&c->d_chunk, ((n_tiles + kChunkTiles - 1) / kChunkTiles + 1) * 256);
+    rc |= dalloc(&c->d_long, n / kWalkCap + 16);
+    rc |= dalloc(&c->d_dup, n);
+    if (rc) { free_buffers(c); return -ENOMEM; }
+    c->cap = n;
+    return 0;
+}
+
+// one stable LSD radix sort of (key, [p64], p32) over `bits` low bits of the key
+// buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
+int radix_sort(mgx_sortdedup* c, u64* key[2], u64* p64[2], u32* p32[2], u32 n, int bits, int* cur) {
+    if (n == 0) return 0;
+    const u32 n_tiles = (n + kTile - 1) / kTile;
+    const u32 n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
+    hipStream_t s = c->compute;
+    for (int shift = 0; shift < bits; shift += 8) {
+        const int in = *cur, out = in ^ 1;
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, c->d_hist);
+        hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, c->d_hist, n_tiles, c->d_chunk);
+        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, s, c->d_chunk, n_chunks);
+        hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, c->d_hist, n_tiles, c->d_chunk);
+        const bool timing = c->ev_used + 2 <= c->ev_scatter.size();
+        if (timing) HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used], s));
+        if (p64)
+            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
+                               p32[in], p32[out], n, shift, c->d_hist);
+        else
+            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
+                               (u64*)nullptr, p32[in], p32[out], n, shift, c->d_hist);
+        if (timing) { HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used + 1], s)); c->ev_used += 2; }
+        c->scatter_bytes += (uint64_t)n * 2 * (8 + 4 + (p64 ? 8 : 0));
+        c->stats.n_radix_passes++;
+        *cur = out;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out) {
+    if (!out) { set_error("out is NULL"); return -EINVAL; }
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        set_error("no HIP device is visible (this library has no CPU fallback)");
+        return -ENODEV;
+    }
+    if (device < 0 || device >= n_dev) { set_error("device %d out of range", device); return -EINVAL; }
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<mgx_sortdedup> c(new (std::nothrow) mgx_sortdedup);
+    if (!c) return -ENOMEM;
+    c->device = device; c->flags = flags;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->d_sc, sizeof(Scalars)));
+    HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_stop));
+    c->ev_scatter.resize(64);
+    for (auto& e : c->ev_scatter) HIP_TRY(hipEventCreate(&e));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipHostMalloc(&c->pinned[i], kPinnedChunk, hipHostMallocDefault));
+        HIP_TRY(hipEventCreate(&c->pin_ev[i]));
+    }
+    *out = c.release();
+    return 0;
+}
+
+void mgx_sortdedup_destroy(mgx_sortdedup_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_buffers(c);
+    (void)hipFree(c->d_indicator); (void)hipFree(c->d_sc);
+    for (int i = 0; i < 2; ++i) { if (c->pinned[i]) (void)hipHostFree(c->pinned[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
+    for (auto e : c->ev_scatter) (void)hipEventDestroy(e);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->compute) (void)hipStreamDestroy(c->compute);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
+    delete c;
+}
+
+int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, const mgx_rec_t* recs) {
+    if (!c) { set_error("ctx is NULL"); return -EINVAL; }
+    if (n_records >= 0xFFFFFFF0ull) { set_error("more than 2^32 records in one shard"); return -E2BIG; }
+    if (n_records && !recs) { set_error("recs is NULL"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, (size_t)n_records);
+    if (rc) { set_error("out of device memory for %llu records", (unsigned long long)n_records); return rc; }
+    // double_pair_indicator: 4L bits like the reference (main.cpp:115)
+    const uint64_t bits = 4 * L + 64;
+    const size_t words = (size_t)((bits + 31) / 32);
+    if (words > c->indicator_cap_words) {
+        (void)hipFree(c->d_indicator); c->d_indicator = nullptr; c->indicator_cap_words = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_indicator, words * 4));
+        c->indicator_cap_words = words;
+    }
+    c->indicator_bits = 4 * L;
+    c->L = L; c->n = (u32)n_records; c->ran = false;
+    // records are streamed through two pinned staging buffers on the copy stream
+    const size_t total = (size_t)n_records * sizeof(mgx_rec_t);
+    size_t off = 0;
+    int buf = 0;
+    while (off < total) {
+        const size_t len = std::min(kPinnedChunk, total - off);
+        HIP_TRY(hipEventSynchronize(c->pin_ev[buf]));
+        memcpy(c->pinned[buf], reinterpret_cast<const char*>(recs) + off, len);
+        HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c->d_recs) + off, c->pinned[buf], len, hipMemcpyHostToDevice, c->copy));
+        HIP_TRY(hipEventRecord(c->pin_ev[buf], c->copy));
+        off += len; buf ^= 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    return 0;
+}
+
+int mgx_sortdedup_run(mgx_sortdedup_t* c) {
+    if (!c) { set_error("ctx is NULL"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->compute;
+    const u32 n = c->n;
+    c->stats = mgx_sortdedup_stats_t{};
+    c->stats.n_records = n;
+    c->ev_used = 0; c->scatter_bytes = 0;
+    HIP_TRY(hipEventRecord(c->ev_start, s));
+    HIP_TRY(hipMemsetAsync(c->d_sc, 0, sizeof(Scalars), s));
+    if (n) {
+        HIP_TRY(hipMemsetAsync(c->d_dup, 0, n, s));
+        HIP_TRY(hipMemsetAsync(c->d_indicator, 0, (size_t)((c->indicator_bits + 64 + 31) / 32) * 4, s));
+        const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
+        hipLaunchKernelGGL(k_build_count, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->d_blk_d, c->d_blk_s, nb, c->d_sc);
+        BuildOut o{c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
+                   c->d_indicator, c->indicator_bits, c->L};
+        hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s, o, c->d_sc);
+        HIP_TRY(hipGetLastError());
+    }
+    // the only host round trip: entry counts and key maxima size the sorts
+    HIP_TRY(hipMemcpyAsync(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const u32 nd = c->sc.n_double, ns = c->sc.n_single;
+    c->stats.n_double = nd; c->stats.n_single = ns;
+    c->stats.key_bits_coord = bits_of(c->sc.max_coord);
+    c->stats.key_bits_pair1 = bits_of(std::max<uint64_t>(c->sc.max_k1d, c->sc.max_k1s));
+    c->stats.key_bits_pair2 = bits_of(c->sc.max_k2d);
+    int rc;
+    // doubles: LSD over (sort_key, mate 5' end): sort by the mate end first, then by sort_key
+    int cur = 0;
+    if ((rc = radix_sort(c, c->d_k2, c->d_k1, c->d_prec, nd, bits_of(c->sc.max_k2d), &cur))) return rc;
+    if ((rc = radix_sort(c, c->d_k1, c->d_k2, c->d_prec, nd, bits_of(c->sc.max_k1d), &cur))) return rc;
+    if (nd) {
+        hipLaunchKernelGGL(k_mark_runs<true>, dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
+                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+        hipLaunchKernelGGL(k_mark_long<true>, dim3(c->n_cu * 2), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
+                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+    }
+    // singles
+    int scur = 0;
+    if ((rc = radix_sort(c, c->d_sk1, nullptr, c->d_srec, ns, bits_of(c->sc.max_k1s), &scur))) return rc;
+    if (ns) {
+        hipLaunchKernelGGL(k_mark_runs<false>, dim3((ns + 255) / 256), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
+                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_s);
+        hipLaunchKernelGGL(k_mark_long<false>, dim3(c->n_cu * 2), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
+                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_s);
+    }
+    // records by unified coordinate (stable: equal coordinates keep arrival order)
+    int ccur = 0;
+    if ((rc = radix_sort(c, c->d_ckey, nullptr, c->d_cval, n, bits_of(c->sc.max_coord), &ccur))) return rc;
+    c->order_buf = ccur;
+    if (n) hipLaunchKernelGGL(k_count_dup, dim3(c->n_cu * 4), dim3(256), 0, s, c->d_dup, n, c->d_sc);
+    HIP_TRY(hipEventRecord(c->ev_stop, s));
+    HIP_TRY(hipGetLastError());
+    c->ran = true;
+    return 0;
+}
+
+int mgx_sortdedup_results(mgx_sortdedup_t* c, uint32_t* out_order, uint8_t* out_dup) {
+    if (!c) { set_error("ctx is NULL"); return -EINVAL; }
+    if (!c->ran) { set_error("mgx_sortdedup_run has not been called"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n) {
+        if (out_order) HIP_TRY(hipMemcpyAsync(out_order, c->d_cval[c->order_buf], (size_t)c->n * 4, hipMemcpyDeviceToHost, c->compute));
+        if (out_dup) HIP_TRY(hipMemcpyAsync(out_dup, c->d_dup, (size_t)c->n, hipMemcpyDeviceToHost, c->compute));
+    }
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+int mgx_sortdedup_stats(mgx_sortdedup_t* c, mgx_sortdedup_stats_t* out) {
+    if (!c || !out) { set_error("NULL argument"); return -EINVAL; }
+    if (!c->ran) { set_error("mgx_sortdedup_run has not been called"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipMemcpy(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost));
+    mgx_sortdedup_stats_t st = c->stats;
+    st.n_dup_records = c->sc.n_dup;
+    HIP_TRY(hipEventElapsedTime(&st.ms_total, c->ev_start, c->ev_stop));
+    st.ms_radix_scatter = 0;
+    for (size_t k = 0; k + 1 < c->ev_used + 1 && k + 1 < c->ev_scatter.size() + 1 && k < c->ev_used; k += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_scatter[k], c->ev_scatter[k + 1]));
+        st.ms_radix_scatter += ms;
+    }
+    st.radix_scatter_bytes = c->scatter_bytes;
+    // LSD-8 traffic model, SURVEY.md section 8d
+    const uint64_t N = c->n, P = (uint64_t)st.n_double + st.n_single;
+    const uint64_t pc = (st.key_bits_coord + 7) / 8, pp = (st.key_bits_pair1 + st.key_bits_pair2 + 7) / 8;
+    st.alg_bytes = N * (8 + pc * 2 * 12) + P * (16 + pp * 2 * 20) + P * 29 + N;
+    *out = st;
+    return 0;
+}
+
+int mgx_sortdedup_sort_mark(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, const mgx_rec_t* recs,
+                            uint32_t* out_order, uint8_t* out_dup) {
+    int rc = mgx_sortdedup_upload(c, L, n_records, recs);
+    if (!rc) rc = mgx_sortdedup_run(c);
+    if (!rc) rc = mgx_sortdedup_results(c, out_order, out_dup);
+    return rc;
+}
+
+}  // extern "C"

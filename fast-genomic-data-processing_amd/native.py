@@ -75,3 +75,34 @@ def check(rc):
     if rc != 0:
         msg = load().mgx_last_error()
         raise MgxError(f"libmgx error {rc}: {msg.decode() if msg else ''}")
+
+
+# ---- include/mgx_sortdedup.h -------------------------------------------------------------------
+class RawRecords(C.Structure):
+    _fields_ = [
+        ("n_records", C.c_uint64), ("flag", C.c_void_p), ("tid", C.c_void_p), ("pos", C.c_void_p),
+        ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("qual_off", C.c_void_p), ("qual", C.c_void_p),
+        ("qname_off", C.c_void_p), ("qname", C.c_void_p), ("n_targets", C.c_uint32), ("target_len", C.c_void_p),
+    ]
+
+
+class SortDedupStats(C.Structure):
+    _fields_ = [
+        ("n_records", C.c_uint64), ("n_double", C.c_uint64), ("n_single", C.c_uint64), ("n_dup_records", C.c_uint64),
+        ("key_bits_coord", C.c_uint32), ("key_bits_pair1", C.c_uint32), ("key_bits_pair2", C.c_uint32),
+        ("n_radix_passes", C.c_uint32), ("ms_total", C.c_float), ("ms_radix_scatter", C.c_float),
+        ("radix_scatter_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
+    ]
+
+
+SORTDEDUP_SYMBOLS = {
+    "mgx_sortdedup_pack": (C.c_int, [C.POINTER(RawRecords), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mgx_sortdedup_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
+    "mgx_sortdedup_destroy": (None, [C.c_void_p]),
+    "mgx_sortdedup_upload": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "mgx_sortdedup_run": (C.c_int, [C.c_void_p]),
+    "mgx_sortdedup_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_sortdedup_stats": (C.c_int, [C.c_void_p, C.POINTER(SortDedupStats)]),
+    "mgx_sortdedup_sort_mark": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+SYMBOLS.update(SORTDEDUP_SYMBOLS)

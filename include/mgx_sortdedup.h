@@ -1,0 +1,106 @@
+/*
+ * mgx_sortdedup.h -- C ABI of the MI355X coordinate-sort + mark-duplicates core (libmgx.so).
+ *
+ * Drop-in seam: the reference has no FFI on this path -- sortmardup is one 600-line main()
+ * (sortmardup/main.cpp) -- so the boundary is cut where its data stops being text/BAM bytes and
+ * becomes fixed-size keys: right after a record has been parsed and paired (main.cpp:160-192),
+ * up to the point where the output order and the duplicate bitmap are consumed by the writer
+ * (main.cpp:359-397).  Reference code replaced, by entry point:
+ *
+ *   mgx_sortdedup_pack   <- BamParser pairing by adjacent qname   sortmardup/tbb/bam_parser.cpp:54-113
+ *                           BAMRecord::score / get_unify_coordinate / prime5_pos
+ *                                                                 sortmardup/tbb/bam_record.cpp:7-62
+ *                           get_tile_x_y / str_to_uint16          sortmardup/tbb/pair.cpp:11-49
+ *                           the arrival order of main.cpp:160-192 with one shuffle thread (-t 1)
+ *                           (host code: byte/pointer work next to the parser)
+ *   mgx_sortdedup_run    <- SinglePair / DoublePair construction  sortmardup/tbb/pair.cpp:51-108
+ *                           double_pair_indicator bitmap          sortmardup/main.cpp:181-192
+ *                           pair sorts + duplicate search         sortmardup/main.cpp:249-281, 299-341
+ *                           stable coordinate sort                sortmardup/main.cpp:348-357
+ *                           duplicate_index lookup per record     sortmardup/main.cpp:385-388
+ *                           (device code: radix sorts + segmented best-of-run scan)
+ *
+ * Out of scope of this ABI: SAM text parsing and BGZF/BAI writing.
+ *
+ * All functions return 0 or a negative errno-style code; mgx_last_error() has the message.
+ */
+#ifndef MGX_SORTDEDUP_H
+#define MGX_SORTDEDUP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_sortdedup mgx_sortdedup_t;
+
+#define MGX_NO_MATE 0xFFFFFFFFu
+
+/* One alignment record reduced to what sorting and duplicate marking need: 32 bytes, the unit
+ * streamed host -> device.  Records are in ARRIVAL order (see mgx_sortdedup_pack). */
+typedef struct mgx_rec {
+    uint64_t coord;   /* unified coordinate kTable[tid] + pos; tid < 0 -> L   (bam_record.cpp:18-24) */
+    uint64_t prime5;  /* unclipped 5' position, uint64 wrap as in the reference (bam_record.cpp:26-62) */
+    uint32_t mate;    /* arrival index of the record paired with this one, or MGX_NO_MATE */
+    uint16_t flag;    /* SAM flag */
+    uint16_t score;   /* sum of base qualities >= 15, uint16 wrap             (bam_record.cpp:7-16) */
+    uint16_t tile, x, y; /* parsed from the qname                             (pair.cpp:22-49) */
+    uint16_t pad_;
+} mgx_rec_t;
+
+/* Parsed alignment records as a BAM reader holds them (structure of arrays, input order). */
+typedef struct mgx_raw_records {
+    uint64_t n_records;
+    const uint16_t* flag;       /* [n] */
+    const int32_t* tid;         /* [n]  (-1 = unmapped '*') */
+    const int64_t* pos;         /* [n]  0-based leftmost position */
+    const uint64_t* cigar_off;  /* [n+1] offsets into cigar */
+    const uint32_t* cigar;      /* BAM encoding: len << 4 | op */
+    const uint64_t* qual_off;   /* [n+1] offsets into qual */
+    const uint8_t* qual;        /* phred values (not ASCII) */
+    const uint64_t* qname_off;  /* [n+1] offsets into qname */
+    const char* qname;          /* concatenated, NOT NUL-terminated */
+    uint32_t n_targets;
+    const uint64_t* target_len; /* [n_targets] @SQ LN */
+} mgx_raw_records_t;
+
+typedef struct mgx_sortdedup_stats {
+    uint64_t n_records, n_double, n_single, n_dup_records;
+    uint32_t key_bits_coord, key_bits_pair1, key_bits_pair2;
+    uint32_t n_radix_passes;        /* scatter launches of the last run */
+    float ms_total;                 /* HIP events around the whole device pipeline (resident input) */
+    float ms_radix_scatter;         /* sum over all radix scatter launches */
+    uint64_t radix_scatter_bytes;   /* algorithmic bytes those launches moved (read + write) */
+    uint64_t alg_bytes;             /* LSD-8 traffic model of SURVEY.md section 8d for this input */
+} mgx_sortdedup_stats_t;
+
+/* Host side (B3-B7): pair records by adjacent equal qname exactly as BamParser does, derive the
+ * per-record keys and emit them in the reference's single-thread arrival order (mates pulled
+ * adjacent).  out_recs and out_input_index must hold n_records entries;
+ * out_input_index[k] = index in `raw` of arrival record k.  *out_L = sum of target lengths. */
+int mgx_sortdedup_pack(const mgx_raw_records_t* raw, mgx_rec_t* out_recs, uint32_t* out_input_index,
+                       uint64_t* out_L);
+
+int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out);
+void mgx_sortdedup_destroy(mgx_sortdedup_t* ctx);
+
+/* Device side.  upload: stream the packed records into HBM (pinned staging, copy stream).
+ * run: radix sorts + duplicate search on the resident records (asynchronous).
+ * results: wait, then copy back
+ *   out_order[k] = arrival index of the k-th record of the coordinate-sorted output
+ *   out_dup[i]   = 1 iff arrival record i gets BAM_FDUP (0x400) set (a pre-existing 0x400 is
+ *                  never cleared, main.cpp:385-388 only ever sets it). */
+int mgx_sortdedup_upload(mgx_sortdedup_t* ctx, uint64_t L, uint64_t n_records, const mgx_rec_t* recs);
+int mgx_sortdedup_run(mgx_sortdedup_t* ctx);
+int mgx_sortdedup_results(mgx_sortdedup_t* ctx, uint32_t* out_order, uint8_t* out_dup);
+int mgx_sortdedup_stats(mgx_sortdedup_t* ctx, mgx_sortdedup_stats_t* out);
+
+/* One shot: upload + run + results. */
+int mgx_sortdedup_sort_mark(mgx_sortdedup_t* ctx, uint64_t L, uint64_t n_records,
+                            const mgx_rec_t* recs, uint32_t* out_order, uint8_t* out_dup);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_SORTDEDUP_H */

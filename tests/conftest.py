@@ -74,3 +74,85 @@ def engine(pkg):
     eng = pkg.PairHMMEngine(0)
     yield eng
     eng.close()
+
+
+RAW_KEYS = ("flag", "tid", "pos", "cigar_off", "cigar", "qual_off", "qual", "qname_off", "qname")
+
+
+class SortDedupOracle:
+    """ctypes handle on oracle/libsortdedup_oracle.so (CPU restatement; checker only)."""
+
+    def __init__(self):
+        _ensure_oracle()
+        so = os.path.join(ROOT, "oracle", "libsortdedup_oracle.so")
+        src = os.path.join(ROOT, "oracle", "sortdedup_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        self.lib = ctypes.CDLL(so)
+        synth = importlib.import_module(PKG + ".synth")
+        self.rec_dtype = synth.REC_DTYPE
+
+    @staticmethod
+    def _raw_args(raw):
+        P = lambda a: np.ascontiguousarray(a).ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        keep = [np.ascontiguousarray(raw[k]) for k in RAW_KEYS] + [np.ascontiguousarray(raw["target_len"])]
+        args = [ctypes.c_uint64(int(raw["n_records"]))] + [P(a) for a in keep[:-1]] + \
+               [ctypes.c_uint32(len(keep[-1])), P(keep[-1])]
+        return args, keep
+
+    def pack(self, raw):
+        n = int(raw["n_records"])
+        recs = np.zeros(n, dtype=self.rec_dtype)
+        idx = np.zeros(n, dtype=np.uint32)
+        L = ctypes.c_uint64()
+        args, keep = self._raw_args(raw)
+        self.lib.sd_oracle_pack(*args, recs.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p),
+                                ctypes.byref(L))
+        return recs, idx, int(L.value)
+
+    def run(self, L, recs):
+        n = len(recs)
+        recs = np.ascontiguousarray(recs)
+        order = np.zeros(n, dtype=np.uint32)
+        dup = np.zeros(n, dtype=np.uint8)
+        counts = np.zeros(3, dtype=np.uint64)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        self.lib.sd_oracle_run(ctypes.c_uint64(L), ctypes.c_uint64(n), P(recs), P(order), P(dup), P(counts))
+        return order, dup, counts
+
+
+class SortDedupRef:
+    """The reference's own classes compiled in place (oracle/_ref/libref_sortdedup.so)."""
+
+    def __init__(self, so):
+        self.lib = ctypes.CDLL(so)
+
+    def run(self, raw):
+        n = int(raw["n_records"])
+        order = np.zeros(n, dtype=np.uint32)
+        dup = np.zeros(n, dtype=np.uint8)
+        arrival = np.zeros(n, dtype=np.uint32)
+        args, keep = SortDedupOracle._raw_args(raw)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        self.lib.ref_sortdedup_run(*args, P(order), P(dup), P(arrival))
+        return order, dup, arrival
+
+
+@pytest.fixture(scope="session")
+def sd_oracle():
+    return SortDedupOracle()
+
+
+@pytest.fixture(scope="session")
+def sd_ref():
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_sortdedup.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_sortdedup.so not built (needs /root/reference)")
+    return SortDedupRef(so)
+
+
+@pytest.fixture(scope="session")
+def sd_engine(pkg):
+    eng = pkg.SortDedupEngine(0)
+    yield eng
+    eng.close()
