@@ -77,6 +77,71 @@ def cpu_baseline(synth, n_sample, seed):
                       f"{d['cells'] / 1e9:.2f} Gcells in {dt:.2f} s wall on {cores} threads"}
 
 
+def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch):
+    """GPU radix sort + duplicate marking over a resident shard of packed records; every rank owns a
+    coordinate-independent shard of its own (weak scaling, no collective on the data path)."""
+    recs, L = synth.gen_sortdedup_packed(args.sort_records, 0x5EED0004 + 0x1000 * rank)
+    eng = pkg.SortDedupEngine(local_rank)
+    t0 = time.perf_counter()
+    eng.upload(L, recs)
+    upload_s = time.perf_counter() - t0
+    for _ in range(2):
+        eng.run()
+    eng.stats()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(local_rank)
+    t0 = time.perf_counter()
+    for _ in range(args.sort_steps):
+        eng.run()
+    st = eng.stats()                      # waits for the stream
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(local_rank)
+    dt = time.perf_counter() - t0
+    tmax = dt
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+    out = None
+    if rank == 0:
+        n = len(recs)
+        ms_scatter_avg = st["ms_radix_scatter"] / max(st["n_radix_passes"], 1)
+        bytes_per_scatter = st["radix_scatter_bytes"] / max(st["n_radix_passes"], 1)
+        achieved = st["radix_scatter_bytes"] / (st["ms_radix_scatter"] * 1e-3) / 1e9
+        out = {"metric": "sortmardup Mrecords/s", "value": n * world * args.sort_steps / tmax / 1e6,
+               "unit": "Mrecords/s", "n_gpus": world, "steps": args.sort_steps, "ms_per_step": tmax / args.sort_steps * 1e3,
+               "dtype": "u64", "scaling": "weak",
+               "config": {"workload": "BASELINE.json configs[3]: synthetic packed BAM records per GPU, 97% in proper "
+                                      "pairs, 10% duplicate pairs, L=3.1e9; radix sorts + duplicate search, records resident in HBM",
+                          "records_per_gpu": n, "n_double": st["n_double"], "n_single": st["n_single"],
+                          "dup_records": st["n_dup_records"], "radix_passes": st["n_radix_passes"]},
+               "device_ms": st["ms_total"], "upload_s": upload_s,
+               "pcie_inclusive_mrecords_s": n / (upload_s + st["ms_total"] * 1e-3) / 1e6,
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "k_radix_scatter (all launches of one run)", "kernel_ms": ms_scatter_avg,
+                            "alg_bytes_per_launch": bytes_per_scatter,
+                            "note": "algorithmic bytes = keys+payload read once and written once per pass"},
+               "model_roofline": {"alg_bytes": st["alg_bytes"], "achieved": st["alg_bytes"] / (st["ms_total"] * 1e-3) / 1e9,
+                                  "unit": "GB/s", "frac": st["alg_bytes"] / (st["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "LSD-8 traffic model of SURVEY.md 8d (307.5 B/record at this config) over the whole pipeline"}}
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from conftest import SortDedupOracle
+            ns = min(n, 4_000_000)
+            orc = SortDedupOracle()
+            t0 = time.perf_counter()
+            orc.run(L, recs[:ns] if ns % 2 == 0 else recs[:ns - 1])
+            cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": ns / cdt / 1e6, "unit": "Mrecords/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} records of the shard (mates kept together), "
+                                             f"serial qsort-based restatement, {cdt:.2f} s"}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +149,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1 << 20, help="test cases per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sort-records", type=int, default=200_000_000,
+                    help="records per GPU for the sortmardup leg (BASELINE.json configs[3]); 0 disables it")
+    ap.add_argument("--sort-steps", type=int, default=5)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,9 +236,17 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(synth, 1 << 18, seed)
-        print(json.dumps(line), flush=True)
     batch.close()
     eng.close()
+
+    # ---- second half of BASELINE.json's metric: sortmardup Mrecords/s (configs[3]) ------------
+    sort_line = None
+    if args.sort_records > 0:
+        sort_line = sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch)
+    if rank == 0:
+        if sort_line is not None:
+            line["sortmardup"] = sort_line
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

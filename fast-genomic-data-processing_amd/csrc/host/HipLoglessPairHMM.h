@@ -1,0 +1,151 @@
+// HipLoglessPairHMM.h -- host-side C++ adapter that puts the MI355X engine behind the reference's
+// PairHMM class boundary (deepmutect/Mutect2Cpp-master/src/utils/pairhmm/PairHMM.h:13-69).
+//
+// It does what VectorLoglessPairHMM does around the native call
+// (utils/pairhmm/VectorLoglessPairHMM.cpp:18-41, 43-148) and nothing more:
+//   initialize()               haplotype table + haplotype -> index map; is_use_trietree_optimize
+//                              is always false (the trie is a CPU-only saving with identical
+//                              results)
+//   computeLog10Likelihoods()  per read: the four quality arrays (&127 like ReadForPairHMM.cpp:34-36),
+//                              de-duplication of identical reads (same bases and same four arrays),
+//                              one test case per (unique read, haplotype), ONE batched call into
+//                              the C ABI instead of the per-test-case loop (:118-119), scatter to
+//                              logLikelihoods->set(alleleIdx, readIdx, value) honouring the allele
+//                              order of the matrix (:135-146)
+//
+// The class is a template over the reference's own types so that it compiles both inside the
+// reference tree (`using HipPairHMM = mgx::HipLoglessPairHMM<RefTraits>;`)
+// and stand-alone against mock types (tests/cpp/test_adapter.cpp).  A Traits type provides:
+//
+//   using Haplotype, Read, Matrix, GcpMap;
+//   static const uint8_t* hap_bases(const Haplotype&);   static int hap_len(const Haplotype&);
+//   static int read_len(const Read&);
+//   static const uint8_t* read_bases(const Read&);       static const uint8_t* read_quals(const Read&);
+//   static std::shared_ptr<uint8_t[]> ins_quals(const std::shared_ptr<Read>&, int len);   // ReadUtils::getBaseInsertionQualities
+//   static std::shared_ptr<uint8_t[]> del_quals(const std::shared_ptr<Read>&, int len);   // ReadUtils::getBaseDeletionQualities
+//   static const char* gcp(GcpMap&, Read*);
+//   static <iterable of shared_ptr<Haplotype>> alleles(Matrix&);   static void set(Matrix&, int allele, int read, double v);
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "mgx_pairhmm.h"
+
+namespace mgx {
+
+template <class Traits>
+class HipLoglessPairHMM {
+public:
+    using Haplotype = typename Traits::Haplotype;
+    using Read = typename Traits::Read;
+    using Matrix = typename Traits::Matrix;
+    using GcpMap = typename Traits::GcpMap;
+
+    // mirrors VectorLoglessPairHMM(PairHMMNativeArgumentCollection&): initNative(useDoublePrecision, threads)
+    explicit HipLoglessPairHMM(bool use_double_precision = false, int device = 0) {
+        if (mgx_pairhmm_create(device, use_double_precision ? MGX_PAIRHMM_FORCE_DOUBLE : 0u, &ctx_) != 0)
+            throw std::runtime_error(std::string("mgx_pairhmm_create: ") + mgx_last_error());
+    }
+    ~HipLoglessPairHMM() { mgx_pairhmm_destroy(ctx_); }
+    HipLoglessPairHMM(const HipLoglessPairHMM&) = delete;
+    HipLoglessPairHMM& operator=(const HipLoglessPairHMM&) = delete;
+
+    bool is_use_trietree_optimize = false;       // read by PairHMMLikelihoodCalculationEngine.cpp:69
+
+    // PairHMM::initialize (the per-sample read list is only used for sizing in the reference)
+    template <class PerSampleReads>
+    void initialize(const std::vector<std::shared_ptr<Haplotype>>& haplotypes, const PerSampleReads&,
+                    int /*readMaxLength*/, int /*haplotypeMaxLength*/) {
+        hap_off_.assign(1, 0);
+        hap_bases_.clear();
+        hap_index_.clear();
+        for (const auto& h : haplotypes) {
+            const int len = Traits::hap_len(*h);
+            const uint8_t* b = Traits::hap_bases(*h);
+            hap_bases_.insert(hap_bases_.end(), b, b + len);
+            hap_off_.push_back(hap_bases_.size());
+            hap_index_.emplace(h.get(), (int)hap_index_.size());
+        }
+        is_use_trietree_optimize = false;
+    }
+
+    void computeLog10Likelihoods(Matrix* logLikelihoods, std::vector<std::shared_ptr<Read>>& processedReads,
+                                 GcpMap* gcp) {
+        if (processedReads.empty()) return;
+        const int n_reads = (int)processedReads.size();
+        const int n_haps = (int)hap_off_.size() - 1;
+        // ---- unique reads (VectorLoglessPairHMM.cpp:71-104): key = quals (masked) + bases
+        std::vector<uint64_t> read_off(1, 0);
+        std::vector<uint8_t> bases, qual, ins, del, gc;
+        std::vector<int> unique_of(n_reads);
+        std::unordered_map<std::string, int> seen;
+        for (int r = 0; r < n_reads; ++r) {
+            const auto& rd = processedReads[r];
+            const int len = Traits::read_len(*rd);
+            auto iq = Traits::ins_quals(rd, len);
+            auto dq = Traits::del_quals(rd, len);
+            const uint8_t* q = Traits::read_quals(*rd);
+            const uint8_t* b = Traits::read_bases(*rd);
+            const char* g = Traits::gcp(*gcp, rd.get());
+            std::string key;
+            key.resize((size_t)5 * len);
+            for (int k = 0; k < len; ++k) {
+                key[k] = (char)(dq[k] & 127);            key[len + k] = (char)(iq[k] & 127);
+                key[2 * len + k] = (char)(g[k] & 127);   key[3 * len + k] = (char)(q[k] & 127);
+                key[4 * len + k] = (char)b[k];
+            }
+            auto it = seen.find(key);
+            if (it != seen.end()) { unique_of[r] = it->second; continue; }
+            const int u = (int)read_off.size() - 1;
+            seen.emplace(std::move(key), u);
+            unique_of[r] = u;
+            bases.insert(bases.end(), b, b + len);
+            qual.insert(qual.end(), q, q + len);
+            ins.insert(ins.end(), iq.get(), iq.get() + len);
+            del.insert(del.end(), dq.get(), dq.get() + len);
+            gc.insert(gc.end(), (const uint8_t*)g, (const uint8_t*)g + len);
+            read_off.push_back(bases.size());
+        }
+        const int n_unique = (int)read_off.size() - 1;
+        // ---- one test case per (unique read, haplotype), read-major like uniqueTestcases
+        std::vector<uint32_t> pair_read((size_t)n_unique * n_haps), pair_hap((size_t)n_unique * n_haps);
+        for (int u = 0; u < n_unique; ++u)
+            for (int h = 0; h < n_haps; ++h) { pair_read[(size_t)u * n_haps + h] = u; pair_hap[(size_t)u * n_haps + h] = h; }
+        mgx_pairhmm_input_t in{};
+        in.n_reads = n_unique; in.read_off = read_off.data();
+        in.bases = bases.data(); in.qual = qual.data(); in.ins = ins.data(); in.del = del.data(); in.gcp = gc.data();
+        in.n_haps = n_haps; in.hap_off = hap_off_.data(); in.hap_bases = hap_bases_.data();
+        in.n_pairs = pair_read.size(); in.pair_read = pair_read.data(); in.pair_hap = pair_hap.data();
+        std::vector<double> out(pair_read.size());
+        if (mgx_pairhmm_compute(ctx_, &in, out.data()) != 0)
+            throw std::runtime_error(std::string("mgx_pairhmm_compute: ") + mgx_last_error());
+        // ---- scatter (VectorLoglessPairHMM.cpp:135-146)
+        for (int r = 0; r < n_reads; ++r) {
+            int hapIdx = 0;
+            for (auto& haplotype : Traits::alleles(*logLikelihoods)) {
+                const int idx = hap_index_.at(haplotype.get());
+                Traits::set(*logLikelihoods, hapIdx, r, out[(size_t)unique_of[r] * n_haps + idx]);
+                hapIdx++;
+            }
+        }
+    }
+    // the reference calls the _trie variants only when is_use_trietree_optimize is true; they are
+    // provided so the virtual interface is complete and return the same values
+    void computeLog10Likelihoods_trie(Matrix* m, std::vector<std::shared_ptr<Read>>& r, GcpMap* g) { computeLog10Likelihoods(m, r, g); }
+    void computeLog10Likelihoods_trie_unique(Matrix* m, std::vector<std::shared_ptr<Read>>& r, GcpMap* g) { computeLog10Likelihoods(m, r, g); }
+
+private:
+    mgx_pairhmm_t* ctx_ = nullptr;
+    std::vector<uint64_t> hap_off_{0};
+    std::vector<uint8_t> hap_bases_;
+    std::unordered_map<const Haplotype*, int> hap_index_;
+};
+
+}  // namespace mgx

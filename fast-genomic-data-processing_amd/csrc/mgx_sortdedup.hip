@@ -82,7 +82,7 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* sm, u32* total) {
 // ---------------------------------------------------------------------------------------------
 // build: classify records, count entries per 1024-record block
 // ---------------------------------------------------------------------------------------------
-constexpr int kBuildBlock = 1024;
+constexpr int kBuildBlock = 8192;
 
 __device__ __forceinline__ int classify(const mgx_rec_t& r, u32 i) {
     // 0 = no entry, 1 = record 1 of a double pair, 2 = single pair
@@ -136,6 +136,7 @@ struct BuildOut {
     u64* sk1; u32* srec;                  // single-pair entries
     u32* indicator; u64 indicator_bits;   // double_pair_indicator, 4L bits
     u64 L;
+    int packed_coord;                     // ckey = coord << 32 | i (every coordinate < 2^32)
 };
 
 __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n, const u32* blk_d, const u32* blk_s,
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
         if (i < n) {
             r = recs[i];
             c = classify(r, i);
-            o.ckey[i] = r.coord; o.cval[i] = i;
+            o.ckey[i] = o.packed_coord ? ((u64)r.coord << 32) | i : (u64)r.coord;
+            if (!o.packed_coord) o.cval[i] = i;
             m_coord = max(m_coord, (u64)r.coord);
         }
         u32 td, ts;
@@ -170,11 +172,6 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
             const u32 at = run_d + pd;
             o.dk1[at] = k1; o.dk2[at] = p2; o.drec[at] = i;
             m_k1d = max(m_k1d, k1); m_k2d = max(m_k2d, p2);
-            // main.cpp:181-192
-            const u64 b2 = p2 + ((orient == 0u || orient == 2u) ? 0ull : o.L);
-            const u64 b1 = p1 + ((orient == 0u || orient == 1u) ? 0ull : o.L);
-            if (b2 < o.indicator_bits) atomicOr(&o.indicator[b2 >> 5], 1u << (b2 & 31));
-            if (b1 < o.indicator_bits) atomicOr(&o.indicator[b1 >> 5], 1u << (b1 & 31));
         } else if (c == 2) {
             // SinglePair::SinglePair, pair.cpp:51-69
             const u64 k1 = (r.prime5 << 2) + ((r.flag & 0x10) ? 3u : 0u);
@@ -252,7 +249,7 @@ __global__ __launch_bounds__(256) void k_radix_apply(u32* __restrict__ hist, u32
     }
 }
 
-template <bool HAS_P64>
+template <bool HAS_P64, bool HAS_P32>
 __global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                        const u64* __restrict__ pin64, u64* __restrict__ pout64,
                                                        const u32* __restrict__ pin32, u32* __restrict__ pout32,
@@ -339,19 +336,44 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ k
             if (i < tile_n) pout64[gpos[k]] = sbuf[i];
         }
     }
-    __syncthreads();
-    u32* sbuf32 = reinterpret_cast<u32*>(sbuf);
+    if constexpr (HAS_P32) {
+        __syncthreads();
+        u32* sbuf32 = reinterpret_cast<u32*>(sbuf);
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const u32 li = wave * (kTile / 4) + k * 64 + lane;
-        if (li < tile_n) sbuf32[lpos[k]] = pin32[tile0 + li];
-    }
-    __syncthreads();
+        for (int k = 0; k < kItems; ++k) {
+            const u32 li = wave * (kTile / 4) + k * 64 + lane;
+            if (li < tile_n) sbuf32[lpos[k]] = pin32[tile0 + li];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const u32 i = k * 256 + tid;
-        if (i < tile_n) pout32[gpos[k]] = sbuf32[i];
+        for (int k = 0; k < kItems; ++k) {
+            const u32 i = k * 256 + tid;
+            if (i < tile_n) pout32[gpos[k]] = sbuf32[i];
+        }
     }
+}
+
+// packed coordinate keys (coord << 32 | arrival index): the order is the low half of the sorted keys
+__global__ __launch_bounds__(256) void k_unpack_order(const u64* __restrict__ keys, u32 n, u32* __restrict__ order) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) order[i] = (u32)keys[i];
+}
+
+// double_pair_indicator (main.cpp:181-192), set from SORTED pair entries so that consecutive lanes
+// touch consecutive words: END = 2 after the sort by mate 5' end (sets the record-2 bits), END = 1
+// after the sort by sort_key (sets the record-1 bits).  Random-order atomics into the 4L-bit map
+// cost a 64-byte read-modify-write each; in sorted order they stay in L2.
+template <int END>
+__global__ __launch_bounds__(256) void k_set_indicator(const u64* __restrict__ k1, const u64* __restrict__ k2, u32 n,
+                                                       u32* __restrict__ indicator, u64 indicator_bits, u64 L) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 a1 = k1[i];
+    const u32 orient = (u32)(a1 & 3);
+    u64 b;
+    if (END == 2) b = k2[i] + ((orient == 0u || orient == 2u) ? 0ull : L);   // record 2 forward: FF, RF
+    else          b = (a1 >> 2) + ((orient == 0u || orient == 1u) ? 0ull : L);   // record 1 forward: FF, FR
+    if (b < indicator_bits) atomicOr(&indicator[b >> 5], 1u << (b & 31));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -495,6 +517,7 @@ struct mgx_sortdedup {
     size_t ev_used = 0;
     uint64_t scatter_bytes = 0;
     int order_buf = 0;                     // which d_cval holds the final order
+    bool packed_coord = false;             // L < 2^32: coordinate sort on packed (coord, index) words
     bool ran = false;
     Scalars sc{};
     mgx_sortdedup_stats_t stats{};
@@ -549,12 +572,12 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
 
 // one stable LSD radix sort of (key, [p64], p32) over `bits` low bits of the key
 // buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
-int radix_sort(mgx_sortdedup* c, u64* key[2], u64* p64[2], u32* p32[2], u32 n, int bits, int* cur) {
+int radix_sort(mgx_sortdedup* c, u64* key[2], u64* p64[2], u32* p32[2], u32 n, int first_shift, int bits, int* cur) {
     if (n == 0) return 0;
     const u32 n_tiles = (n + kTile - 1) / kTile;
     const u32 n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
     hipStream_t s = c->compute;
-    for (int shift = 0; shift < bits; shift += 8) {
+    for (int shift = first_shift; shift < first_shift + bits; shift += 8) {
         const int in = *cur, out = in ^ 1;
         hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, c->d_hist);
         hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, c->d_hist, n_tiles, c->d_chunk);
@@ -563,13 +586,16 @@ int radix_sort(mgx_sortdedup* c, u64* key[2], u64* p64[2], u32* p32[2], u32 n, i
         const bool timing = c->ev_used + 2 <= c->ev_scatter.size();
         if (timing) HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used], s));
         if (p64)
-            hipLaunchKernelGGL(k_radix_scatter<true>, dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
+            hipLaunchKernelGGL((k_radix_scatter<true, true>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
                                p32[in], p32[out], n, shift, c->d_hist);
-        else
-            hipLaunchKernelGGL(k_radix_scatter<false>, dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
+        else if (p32)
+            hipLaunchKernelGGL((k_radix_scatter<false, true>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
                                (u64*)nullptr, p32[in], p32[out], n, shift, c->d_hist);
+        else
+            hipLaunchKernelGGL((k_radix_scatter<false, false>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
+                               (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, c->d_hist);
         if (timing) { HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used + 1], s)); c->ev_used += 2; }
-        c->scatter_bytes += (uint64_t)n * 2 * (8 + 4 + (p64 ? 8 : 0));
+        c->scatter_bytes += (uint64_t)n * 2 * (8 + (p32 ? 4 : 0) + (p64 ? 8 : 0));
         c->stats.n_radix_passes++;
         *cur = out;
     }
@@ -642,6 +668,7 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
     }
     c->indicator_bits = 4 * L;
     c->L = L; c->n = (u32)n_records; c->ran = false;
+    c->packed_coord = L < 0xFFFFFFFFull;     // coord <= L (bam_record.cpp:18-24)
     // records are streamed through two pinned staging buffers on the copy stream
     const size_t total = (size_t)n_records * sizeof(mgx_rec_t);
     size_t off = 0;
@@ -667,21 +694,27 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     c->stats.n_records = n;
     c->ev_used = 0; c->scatter_bytes = 0;
     HIP_TRY(hipEventRecord(c->ev_start, s));
-    HIP_TRY(hipMemsetAsync(c->d_sc, 0, sizeof(Scalars), s));
-    if (n) {
-        HIP_TRY(hipMemsetAsync(c->d_dup, 0, n, s));
-        HIP_TRY(hipMemsetAsync(c->d_indicator, 0, (size_t)((c->indicator_bits + 64 + 31) / 32) * 4, s));
-        const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
-        hipLaunchKernelGGL(k_build_count, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->d_blk_d, c->d_blk_s, nb, c->d_sc);
-        BuildOut o{c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
-                   c->d_indicator, c->indicator_bits, c->L};
-        hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s, o, c->d_sc);
-        HIP_TRY(hipGetLastError());
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipMemsetAsync(c->d_sc, 0, sizeof(Scalars), s));
+        if (n) {
+            HIP_TRY(hipMemsetAsync(c->d_dup, 0, n, s));
+            HIP_TRY(hipMemsetAsync(c->d_indicator, 0, (size_t)((c->indicator_bits + 64 + 31) / 32) * 4, s));
+            const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
+            hipLaunchKernelGGL(k_build_count, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s);
+            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->d_blk_d, c->d_blk_s, nb, c->d_sc);
+            BuildOut o{c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
+                       c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0};
+            hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s, o, c->d_sc);
+            HIP_TRY(hipGetLastError());
+        }
+        // the only host round trip: entry counts and key maxima size the sorts
+        HIP_TRY(hipMemcpyAsync(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // a coordinate beyond L (a position past the end of its contig) does not fit the packed
+        // (coord << 32 | index) key: rebuild once with separate key/value arrays
+        if (c->packed_coord && c->sc.max_coord >= (1ull << 32)) { c->packed_coord = false; continue; }
+        break;
     }
-    // the only host round trip: entry counts and key maxima size the sorts
-    HIP_TRY(hipMemcpyAsync(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
     const u32 nd = c->sc.n_double, ns = c->sc.n_single;
     c->stats.n_double = nd; c->stats.n_single = ns;
     c->stats.key_bits_coord = bits_of(c->sc.max_coord);
@@ -690,9 +723,13 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     int rc;
     // doubles: LSD over (sort_key, mate 5' end): sort by the mate end first, then by sort_key
     int cur = 0;
-    if ((rc = radix_sort(c, c->d_k2, c->d_k1, c->d_prec, nd, bits_of(c->sc.max_k2d), &cur))) return rc;
-    if ((rc = radix_sort(c, c->d_k1, c->d_k2, c->d_prec, nd, bits_of(c->sc.max_k1d), &cur))) return rc;
+    if ((rc = radix_sort(c, c->d_k2, c->d_k1, c->d_prec, nd, 0, bits_of(c->sc.max_k2d), &cur))) return rc;
+    if (nd) hipLaunchKernelGGL(k_set_indicator<2>, dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd,
+                               c->d_indicator, c->indicator_bits, c->L);
+    if ((rc = radix_sort(c, c->d_k1, c->d_k2, c->d_prec, nd, 0, bits_of(c->sc.max_k1d), &cur))) return rc;
     if (nd) {
+        hipLaunchKernelGGL(k_set_indicator<1>, dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd,
+                           c->d_indicator, c->indicator_bits, c->L);
         hipLaunchKernelGGL(k_mark_runs<true>, dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
                            c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_d);
         hipLaunchKernelGGL(k_mark_long<true>, dim3(c->n_cu * 2), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
@@ -700,7 +737,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     }
     // singles
     int scur = 0;
-    if ((rc = radix_sort(c, c->d_sk1, nullptr, c->d_srec, ns, bits_of(c->sc.max_k1s), &scur))) return rc;
+    if ((rc = radix_sort(c, c->d_sk1, nullptr, c->d_srec, ns, 0, bits_of(c->sc.max_k1s), &scur))) return rc;
     if (ns) {
         hipLaunchKernelGGL(k_mark_runs<false>, dim3((ns + 255) / 256), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
                            c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_s);
@@ -709,7 +746,14 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     }
     // records by unified coordinate (stable: equal coordinates keep arrival order)
     int ccur = 0;
-    if ((rc = radix_sort(c, c->d_ckey, nullptr, c->d_cval, n, bits_of(c->sc.max_coord), &ccur))) return rc;
+    if (c->packed_coord) {
+        // key = coord << 32 | arrival index: sort on the high half only, 8 bytes per record per pass
+        if ((rc = radix_sort(c, c->d_ckey, nullptr, nullptr, n, 32, bits_of(c->sc.max_coord), &ccur))) return rc;
+        if (n) hipLaunchKernelGGL(k_unpack_order, dim3((n + 255) / 256), dim3(256), 0, s, c->d_ckey[ccur], n, c->d_cval[0]);
+        ccur = 0;
+    } else {
+        if ((rc = radix_sort(c, c->d_ckey, nullptr, c->d_cval, n, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
+    }
     c->order_buf = ccur;
     if (n) hipLaunchKernelGGL(k_count_dup, dim3(c->n_cu * 4), dim3(256), 0, s, c->d_dup, n, c->d_sc);
     HIP_TRY(hipEventRecord(c->ev_stop, s));

@@ -1,0 +1,72 @@
+// tests/cpp/test_adapter.cpp -- drives mgx::HipLoglessPairHMM (the C++ mirror of the reference's
+// PairHMM class boundary) with mock Haplotype / SAMRecord / SampleMatrix types and prints the
+// likelihood matrix; tests/test_adapter_gpu.py compares it with the oracle.
+//   g++ -std=c++17 -I include -I fast-genomic-data-processing_amd/csrc/host tests/cpp/test_adapter.cpp -L<pkg> -lmgx
+#include <cstdio>
+#include <cstdlib>
+#include <list>
+#include <map>
+#include <string>
+
+#include "HipLoglessPairHMM.h"
+
+struct MockHap { std::vector<uint8_t> b; };
+struct MockRead { std::vector<uint8_t> bases, quals, ins, del; };
+struct MockMatrix {
+    std::list<std::shared_ptr<MockHap>> order;       // allele order of the matrix (differs from the list order)
+    int n_reads;
+    std::vector<double> v;
+    std::list<std::shared_ptr<MockHap>>& alleles() { return order; }
+    void set(int a, int r, double x) { v[(size_t)a * n_reads + r] = x; }
+};
+using MockGcp = std::map<MockRead*, std::shared_ptr<char[]>>;
+
+struct MockTraits {
+    using Haplotype = MockHap; using Read = MockRead; using Matrix = MockMatrix; using GcpMap = MockGcp;
+    static const uint8_t* hap_bases(const MockHap& h) { return h.b.data(); }
+    static int hap_len(const MockHap& h) { return (int)h.b.size(); }
+    static int read_len(const MockRead& r) { return (int)r.bases.size(); }
+    static const uint8_t* read_bases(const MockRead& r) { return r.bases.data(); }
+    static const uint8_t* read_quals(const MockRead& r) { return r.quals.data(); }
+    static std::shared_ptr<uint8_t[]> copy(const std::vector<uint8_t>& v) { std::shared_ptr<uint8_t[]> p(new uint8_t[v.size()]); memcpy(p.get(), v.data(), v.size()); return p; }
+    static std::shared_ptr<uint8_t[]> ins_quals(const std::shared_ptr<MockRead>& r, int) { return copy(r->ins); }
+    static std::shared_ptr<uint8_t[]> del_quals(const std::shared_ptr<MockRead>& r, int) { return copy(r->del); }
+    static const char* gcp(MockGcp& g, MockRead* r) { return g.at(r).get(); }
+    static std::list<std::shared_ptr<MockHap>>& alleles(MockMatrix& m) { return m.alleles(); }
+    static void set(MockMatrix& m, int a, int r, double v) { m.set(a, r, v); }
+};
+
+// input file: n_haps n_reads, then per hap: bases; per read: bases quals(ints) ...  (written by the test)
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    FILE* f = fopen(argv[1], "r");
+    if (!f) return 2;
+    int n_haps, n_reads;
+    if (fscanf(f, "%d %d", &n_haps, &n_reads) != 2) return 2;
+    std::vector<std::shared_ptr<MockHap>> haps;
+    char buf[8192];
+    for (int h = 0; h < n_haps; ++h) {
+        if (fscanf(f, "%8191s", buf) != 1) return 2;
+        auto p = std::make_shared<MockHap>(); p->b.assign(buf, buf + strlen(buf)); haps.push_back(p);
+    }
+    std::vector<std::shared_ptr<MockRead>> reads;
+    MockGcp gcp;
+    for (int r = 0; r < n_reads; ++r) {
+        if (fscanf(f, "%8191s", buf) != 1) return 2;
+        auto p = std::make_shared<MockRead>(); p->bases.assign(buf, buf + strlen(buf));
+        const size_t n = p->bases.size();
+        std::shared_ptr<char[]> g(new char[n]);
+        for (auto* v : {&p->quals, &p->ins, &p->del}) { v->resize(n); for (size_t k = 0; k < n; ++k) { int x; if (fscanf(f, "%d", &x) != 1) return 2; (*v)[k] = (uint8_t)x; } }
+        for (size_t k = 0; k < n; ++k) { int x; if (fscanf(f, "%d", &x) != 1) return 2; g[k] = (char)x; }
+        gcp[p.get()] = g; reads.push_back(p);
+    }
+    fclose(f);
+    mgx::HipLoglessPairHMM<MockTraits> hmm(false, 0);
+    std::map<std::string, std::vector<std::shared_ptr<MockRead>>> per_sample{{"s", reads}};
+    hmm.initialize(haps, per_sample, 0, 0);
+    MockMatrix m; m.n_reads = n_reads; m.v.assign((size_t)n_haps * n_reads, 0.0);
+    for (int h = n_haps - 1; h >= 0; --h) m.order.push_back(haps[h]);      // reversed allele order on purpose
+    hmm.computeLog10Likelihoods(&m, reads, &gcp);
+    for (int a = 0; a < n_haps; ++a) { for (int r = 0; r < n_reads; ++r) printf("%.17g ", m.v[(size_t)a * n_reads + r]); printf("\n"); }
+    return 0;
+}

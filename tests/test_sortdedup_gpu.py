@@ -22,7 +22,7 @@ def test_golden_file(pkg, sd_engine):
 
 @pytest.mark.parametrize("n_templates,seed,kw", [
     (3000, 21, {}), (20000, 22, dict(dup_rate=0.5)), (5000, 23, dict(qname_style="plain")),   # total ties
-    (7, 24, {}), (1, 25, {}), (40000, 26, dict(n_contigs=2, contig_len=3000, dup_rate=0.0)),   # dense: long runs
+    (7, 24, {}), (1, 25, {}), (40000, 26, dict(n_contigs=2, contig_len=5000, dup_rate=0.0)),   # dense: long runs
 ])
 def test_raw_random_vs_oracle(pkg, sd_engine, sd_oracle, synth, n_templates, seed, kw):
     raw = synth.gen_sortdedup_raw(n_templates, seed, **kw)
