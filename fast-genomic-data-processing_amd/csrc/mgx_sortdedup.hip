@@ -91,45 +91,6 @@ __device__ __forceinline__ int classify(const mgx_rec_t& r, u32 i) {
     return r.mate > i ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_build_count(const mgx_rec_t* recs, u32 n, u32* blk_d, u32* blk_s) {
-    __shared__ u32 sm[8];
-    const u32 base = blockIdx.x * kBuildBlock;
-    u32 cd = 0, cs = 0;
-    for (int k = 0; k < kBuildBlock / 256; ++k) {
-        const u32 i = base + k * 256 + threadIdx.x;
-        if (i < n) {
-            const int c = classify(recs[i], i);
-            cd += c == 1; cs += c == 2;
-        }
-    }
-    u32 td, ts;
-    block_excl_scan_256(cd, sm, &td);
-    block_excl_scan_256(cs, sm + 4, &ts);
-    if (threadIdx.x == 0) { blk_d[blockIdx.x] = td; blk_s[blockIdx.x] = ts; }
-}
-
-// single-block exclusive scan of up to a few million u32 (block counts), in place; totals out
-__global__ __launch_bounds__(1024) void k_scan_counts(u32* a, u32* b, u32 n, Scalars* sc) {
-    __shared__ u32 part[2][1024];
-    const u32 per = (n + 1023) / 1024;
-    const u32 lo = threadIdx.x * per, hi = min(n, lo + per);
-    u32 sa = 0, sb = 0;
-    for (u32 i = lo; i < hi; ++i) { sa += a[i]; sb += b[i]; }
-    part[0][threadIdx.x] = sa; part[1][threadIdx.x] = sb;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 ra = 0, rb = 0;
-        for (int t = 0; t < 1024; ++t) {
-            const u32 xa = part[0][t], xb = part[1][t];
-            part[0][t] = ra; part[1][t] = rb; ra += xa; rb += xb;
-        }
-        sc->n_double = ra; sc->n_single = rb;
-    }
-    __syncthreads();
-    u32 ra = part[0][threadIdx.x], rb = part[1][threadIdx.x];
-    for (u32 i = lo; i < hi; ++i) { const u32 xa = a[i], xb = b[i]; a[i] = ra; b[i] = rb; ra += xa; rb += xb; }
-}
-
 struct BuildOut {
     u64* ckey; u32* cval;                 // coordinate sort input
     u64* dk1; u64* dk2; u32* drec;        // double-pair entries (compacted, arrival order)
@@ -137,14 +98,43 @@ struct BuildOut {
     u32* indicator; u64 indicator_bits;   // double_pair_indicator, 4L bits
     u64 L;
     int packed_coord;                     // ckey = coord << 32 | i (every coordinate < 2^32)
+    int packed_pair;                      // dk2 = mate 5' end << 32 | record (every 5' end < 2^32)
 };
 
-__global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n, const u32* blk_d, const u32* blk_s,
-                                                    BuildOut o, Scalars* sc) {
-    __shared__ u32 sm[8];
+// Entries are compacted with one global atomic per wavefront and kind, so their order is not the
+// arrival order; nothing downstream depends on it: runs are formed by key equality and total ties
+// between entries are broken by the record index itself (k_mark_runs), not by position.
+__global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n, BuildOut o, Scalars* sc) {
     __shared__ u64 smax[4][4];
+    __shared__ u32 s_cnt[2], s_base[2];
     const u32 base = blockIdx.x * kBuildBlock;
-    u32 run_d = blk_d[blockIdx.x], run_s = blk_s[blockIdx.x];
+    const u64 lt = lanemask_lt();
+    // pass A: how many entries of each kind does this block produce -> ONE global atomic per kind
+    // (a single counter word sustains only ~90 atomics/us: never one per wavefront)
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        u32 cd = 0, cs = 0;
+        for (int k = 0; k < kBuildBlock / 256; ++k) {
+            const u32 i = base + k * 256 + threadIdx.x;
+            if (i < n) {
+                // classify() needs flag and mate only: bytes 16..21 of the 32-byte record
+                const u32 mate = recs[i].mate; const u32 flag = recs[i].flag;
+                const int c = (flag & kIgnorable) ? 0 : (mate == MGX_NO_MATE ? 2 : (mate > i ? 1 : 0));
+                cd += c == 1; cs += c == 2;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { cd += __shfl_xor(cd, off, 64); cs += __shfl_xor(cs, off, 64); }
+        if ((threadIdx.x & 63) == 0) { if (cd) atomicAdd(&s_cnt[0], cd); if (cs) atomicAdd(&s_cnt[1], cs); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const u32 cnt = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = cnt ? atomicAdd(threadIdx.x == 0 ? &sc->n_double : &sc->n_single, cnt) : 0u;
+        s_cnt[threadIdx.x] = 0;                 // reused below as the block-local running offset
+    }
+    __syncthreads();
     u64 m_coord = 0, m_k1d = 0, m_k2d = 0, m_k1s = 0;
     for (int k = 0; k < kBuildBlock / 256; ++k) {
         const u32 i = base + k * 256 + threadIdx.x;
@@ -157,9 +147,13 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
             if (!o.packed_coord) o.cval[i] = i;
             m_coord = max(m_coord, (u64)r.coord);
         }
-        u32 td, ts;
-        const u32 pd = block_excl_scan_256(c == 1, sm, &td);
-        const u32 ps = block_excl_scan_256(c == 2, sm + 4, &ts);
+        const u64 bd = __ballot(c == 1), bs = __ballot(c == 2);
+        u32 based = 0, bases = 0;
+        if ((threadIdx.x & 63) == 0) {
+            if (bd) based = atomicAdd(&s_cnt[0], (u32)__popcll(bd));      // LDS
+            if (bs) bases = atomicAdd(&s_cnt[1], (u32)__popcll(bs));
+        }
+        based = __shfl(based, 0, 64) + s_base[0]; bases = __shfl(bases, 0, 64) + s_base[1];
         if (c == 1) {
             // DoublePair::DoublePair, pair.cpp:71-108
             const mgx_rec_t m = recs[r.mate];
@@ -169,17 +163,17 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
             u32 orient = f1 ? (f2 ? 0u : 1u) : (f2 ? 2u : 3u);       // FF FR RF RR
             if (p1 == p2 && orient == 2u) orient = 1u;
             const u64 k1 = (p1 << 2) + orient;
-            const u32 at = run_d + pd;
-            o.dk1[at] = k1; o.dk2[at] = p2; o.drec[at] = i;
+            const u32 at = based + (u32)__popcll(bd & lt);
+            o.dk1[at] = k1;
+            if (o.packed_pair) o.dk2[at] = (p2 << 32) | i; else { o.dk2[at] = p2; o.drec[at] = i; }
             m_k1d = max(m_k1d, k1); m_k2d = max(m_k2d, p2);
         } else if (c == 2) {
             // SinglePair::SinglePair, pair.cpp:51-69
             const u64 k1 = (r.prime5 << 2) + ((r.flag & 0x10) ? 3u : 0u);
-            const u32 at = run_s + ps;
+            const u32 at = bases + (u32)__popcll(bs & lt);
             o.sk1[at] = k1; o.srec[at] = i;
             m_k1s = max(m_k1s, k1);
         }
-        run_d += td; run_s += ts;
     }
     // block max -> 4 global atomics
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,7 +357,7 @@ __global__ __launch_bounds__(256) void k_unpack_order(const u64* __restrict__ ke
 // touch consecutive words: END = 2 after the sort by mate 5' end (sets the record-2 bits), END = 1
 // after the sort by sort_key (sets the record-1 bits).  Random-order atomics into the 4L-bit map
 // cost a 64-byte read-modify-write each; in sorted order they stay in L2.
-template <int END>
+template <int END, bool PK>
 __global__ __launch_bounds__(256) void k_set_indicator(const u64* __restrict__ k1, const u64* __restrict__ k2, u32 n,
                                                        u32* __restrict__ indicator, u64 indicator_bits, u64 L) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
@@ -371,16 +365,54 @@ __global__ __launch_bounds__(256) void k_set_indicator(const u64* __restrict__ k
     const u64 a1 = k1[i];
     const u32 orient = (u32)(a1 & 3);
     u64 b;
-    if (END == 2) b = k2[i] + ((orient == 0u || orient == 2u) ? 0ull : L);   // record 2 forward: FF, RF
+    if (END == 2) b = (PK ? (k2[i] >> 32) : k2[i]) + ((orient == 0u || orient == 2u) ? 0ull : L);   // record 2 forward: FF, RF
     else          b = (a1 >> 2) + ((orient == 0u || orient == 1u) ? 0ull : L);   // record 1 forward: FF, FR
     if (b < indicator_bits) atomicOr(&indicator[b >> 5], 1u << (b & 31));
+}
+
+// Tiled form of the same bitmap, used whenever every 5' end lies below L - 64 (always, except for
+// positions wrapped below zero or clipped past the last contig): the reverse-strand half then
+// starts at Lp = L rounded up to a whole tile instead of L -- no forward bit can reach it, so the
+// answers are unchanged -- and each workgroup OWNS kIndTile positions of both halves: it finds its
+// slice of the sorted entries by binary search, sets bits in LDS and writes whole words with plain
+// coalesced stores.  No global atomics and no memset of the 4L-bit map.
+constexpr u32 kIndTile = 65536;              // positions per workgroup (2 x 8 KB of LDS)
+template <int END, bool PK>
+__global__ __launch_bounds__(256) void k_indicator_tiles(const u64* __restrict__ k1, const u64* __restrict__ k2, u32 n,
+                                                         u32* __restrict__ indicator, u64 Lp) {
+    __shared__ u32 fw[kIndTile / 32], rv[kIndTile / 32];
+    __shared__ u32 s_lo, s_hi;
+    auto POS = [&](u32 t) -> u64 { return END == 2 ? (PK ? (k2[t] >> 32) : k2[t]) : (k1[t] >> 2); };
+    for (u32 w = threadIdx.x; w < kIndTile / 32; w += 256) { fw[w] = 0; rv[w] = 0; }
+    const u64 pos_lo = (u64)blockIdx.x * kIndTile, pos_hi = pos_lo + kIndTile;
+    if (threadIdx.x < 2) {
+        const u64 target = threadIdx.x == 0 ? pos_lo : pos_hi;
+        u32 a = 0, b = n;                                   // first entry with POS >= target
+        while (a < b) { const u32 m = a + (b - a) / 2; if (POS(m) < target) a = m + 1; else b = m; }
+        if (threadIdx.x == 0) s_lo = a; else s_hi = a;
+    }
+    __syncthreads();
+    const u32 lo = s_lo, hi = s_hi;
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
+        const u32 orient = (u32)(k1[i] & 3);
+        const u32 p = (u32)(POS(i) - pos_lo);
+        const bool fwd = END == 2 ? (orient == 0u || orient == 2u) : (orient == 0u || orient == 1u);
+        atomicOr(fwd ? &fw[p >> 5] : &rv[p >> 5], 1u << (p & 31));
+    }
+    __syncthreads();
+    u32* gf = indicator + (size_t)blockIdx.x * (kIndTile / 32);
+    u32* gr = indicator + (size_t)(Lp >> 5) + (size_t)blockIdx.x * (kIndTile / 32);
+    for (u32 w = threadIdx.x; w < kIndTile / 32; w += 256) {
+        if (END == 2) { gf[w] = fw[w]; gr[w] = rv[w]; }                       // first pass: defines every word
+        else { if (fw[w]) gf[w] |= fw[w]; if (rv[w]) gr[w] |= rv[w]; }        // second pass: this tile owns them
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // best-of-run and duplicate marking
 // ---------------------------------------------------------------------------------------------
 // quality of a pair entry: smaller is better -- score descending, then tile, x, y ascending
-// (main.cpp:253-264 / 303-314); sorted position breaks total ties (= arrival order, LSD is stable)
+// (main.cpp:253-264 / 303-314); the record index (= arrival order) breaks total ties
 __device__ __forceinline__ u64 quality_double(const mgx_rec_t* recs, u32 rec) {
     const mgx_rec_t a = recs[rec];
     const mgx_rec_t b = recs[a.mate];
@@ -394,75 +426,81 @@ __device__ __forceinline__ u64 quality_single(const mgx_rec_t* recs, u32 rec) {
 
 // One lane per run head walks its run (runs are short); runs longer than kWalkCap go to a list
 // that k_mark_long handles with a whole workgroup each.
-template <bool DOUBLE>
+// PK: the second array holds (mate 5' end << 32 | record) packed in one word and `rec` is unused
+template <bool DOUBLE, bool PK>
 __global__ __launch_bounds__(256) void k_mark_runs(const u64* __restrict__ k1, const u64* __restrict__ k2,
                                                    const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
                                                    uint8_t* __restrict__ dup, u32* __restrict__ long_list, u32* n_long) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const u64 a1 = k1[i], a2 = DOUBLE ? k2[i] : 0;
-    if (i > 0 && k1[i - 1] == a1 && (!DOUBLE || k2[i - 1] == a2)) return;      // not a run head
+    auto K2 = [&](u32 t) -> u64 { return !DOUBLE ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
+    auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
+    const u64 a1 = k1[i], a2 = K2(i);
+    if (i > 0 && k1[i - 1] == a1 && (!DOUBLE || K2(i - 1) == a2)) return;      // not a run head
     u32 best = i;
-    u64 bq = DOUBLE ? quality_double(recs, rec[i]) : quality_single(recs, rec[i]);
+    u64 bq = DOUBLE ? quality_double(recs, REC(i)) : quality_single(recs, REC(i));
     u32 j = i + 1;
     for (; j < n && j - i < kWalkCap; ++j) {
-        if (k1[j] != a1 || (DOUBLE && k2[j] != a2)) break;
-        const u64 q = DOUBLE ? quality_double(recs, rec[j]) : quality_single(recs, rec[j]);
-        if (q < bq) { bq = q; best = j; }
+        if (k1[j] != a1 || (DOUBLE && K2(j) != a2)) break;
+        const u64 q = DOUBLE ? quality_double(recs, REC(j)) : quality_single(recs, REC(j));
+        if (q < bq || (q == bq && REC(j) < REC(best))) { bq = q; best = j; }
     }
-    if (j < n && j - i >= kWalkCap && k1[j] == a1 && (!DOUBLE || k2[j] == a2)) {
+    if (j < n && j - i >= kWalkCap && k1[j] == a1 && (!DOUBLE || K2(j) == a2)) {
         long_list[atomicAdd(n_long, 1u)] = i;                                     // long run: defer
         return;
     }
     if (!DOUBLE) {
         // main.cpp:325-331: the kept single is a duplicate iff a double pair has an end there
         u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
-        if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[rec[best]] = 1;
+        if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[REC(best)] = 1;
     }
     for (u32 t = i; t < j; ++t) {
         if (t == best) continue;
-        const u32 r = rec[t];
+        const u32 r = REC(t);
         dup[r] = 1;
         if (DOUBLE) dup[recs[r].mate] = 1;
     }
 }
 
-template <bool DOUBLE>
+template <bool DOUBLE, bool PK>
 __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, const u64* __restrict__ k2,
                                                    const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
                                                    uint8_t* __restrict__ dup, const u32* __restrict__ long_list, const u32* n_long) {
     __shared__ u64 sq[256];
     __shared__ u32 sp[256];
+    __shared__ u32 sr[256];
     __shared__ u32 s_end;
+    auto K2 = [&](u32 t) -> u64 { return !DOUBLE ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
+    auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
     for (u32 li = blockIdx.x; li < *n_long; li += gridDim.x) {
         const u32 i = long_list[li];
-        const u64 a1 = k1[i], a2 = DOUBLE ? k2[i] : 0;
+        const u64 a1 = k1[i], a2 = K2(i);
         // pass 1: extent of the run and its best entry
-        u64 bq = ~0ull; u32 bp = 0xFFFFFFFFu;
+        u64 bq = ~0ull; u32 bp = 0xFFFFFFFFu, bpr = 0xFFFFFFFFu;
         u32 end = n;
         for (u32 c = i; c < n; c += 256) {
             const u32 t = c + threadIdx.x;
-            const bool in = t < n && k1[t] == a1 && (!DOUBLE || k2[t] == a2);
+            const bool in = t < n && k1[t] == a1 && (!DOUBLE || K2(t) == a2);
             if (threadIdx.x == 0) s_end = n;
             __syncthreads();
             if (t < n && !in) atomicMin(&s_end, t);
             __syncthreads();
             const u32 e = s_end;
             if (t < e) {
-                const u64 q = DOUBLE ? quality_double(recs, rec[t]) : quality_single(recs, rec[t]);
-                if (q < bq || (q == bq && t < bp)) { bq = q; bp = t; }
+                const u64 q = DOUBLE ? quality_double(recs, REC(t)) : quality_single(recs, REC(t));
+                if (q < bq || (q == bq && REC(t) < bpr)) { bq = q; bp = t; bpr = REC(t); }
             }
             __syncthreads();
             if (e < n) { end = e; break; }
         }
-        sq[threadIdx.x] = bq; sp[threadIdx.x] = bp;
+        sq[threadIdx.x] = bq; sp[threadIdx.x] = bp; sr[threadIdx.x] = bpr;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
             if ((int)threadIdx.x < s) {
-                const u64 q = sq[threadIdx.x + s]; const u32 p = sp[threadIdx.x + s];
-                if (q < sq[threadIdx.x] || (q == sq[threadIdx.x] && p < sp[threadIdx.x])) { sq[threadIdx.x] = q; sp[threadIdx.x] = p; }
+                const u64 q = sq[threadIdx.x + s]; const u32 p = sp[threadIdx.x + s], r = sr[threadIdx.x + s];
+                if (q < sq[threadIdx.x] || (q == sq[threadIdx.x] && r < sr[threadIdx.x])) { sq[threadIdx.x] = q; sp[threadIdx.x] = p; sr[threadIdx.x] = r; }
             }
             __syncthreads();
         }
@@ -470,11 +508,11 @@ __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, c
         __syncthreads();
         if (!DOUBLE && threadIdx.x == 0) {
             u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
-            if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[rec[best]] = 1;
+            if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[REC(best)] = 1;
         }
         for (u32 t = i + threadIdx.x; t < end; t += 256) {
             if (t == best) continue;
-            const u32 r = rec[t];
+            const u32 r = REC(t);
             dup[r] = 1;
             if (DOUBLE) dup[recs[r].mate] = 1;
         }
@@ -506,7 +544,7 @@ struct mgx_sortdedup {
     u64 *d_ckey[2] = {nullptr, nullptr}; u32* d_cval[2] = {nullptr, nullptr};
     u64 *d_k1[2] = {nullptr, nullptr}, *d_k2[2] = {nullptr, nullptr}; u32* d_prec[2] = {nullptr, nullptr};
     u64* d_sk1[2] = {nullptr, nullptr}; u32* d_srec[2] = {nullptr, nullptr};
-    u32 *d_blk_d = nullptr, *d_blk_s = nullptr, *d_hist = nullptr, *d_chunk = nullptr, *d_long = nullptr;
+    u32 *d_hist = nullptr, *d_chunk = nullptr, *d_long = nullptr;
     u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
     uint8_t* d_dup = nullptr;
     Scalars* d_sc = nullptr;
@@ -518,6 +556,7 @@ struct mgx_sortdedup {
     uint64_t scatter_bytes = 0;
     int order_buf = 0;                     // which d_cval holds the final order
     bool packed_coord = false;             // L < 2^32: coordinate sort on packed (coord, index) words
+    bool packed_pair = false;              // every 5' end < 2^32: (mate end, record) ride in one word
     bool ran = false;
     Scalars sc{};
     mgx_sortdedup_stats_t stats{};
@@ -535,9 +574,9 @@ void free_buffers(mgx_sortdedup* c) {
         c->d_ckey[i] = c->d_k1[i] = c->d_k2[i] = c->d_sk1[i] = nullptr;
         c->d_cval[i] = c->d_prec[i] = c->d_srec[i] = nullptr;
     }
-    (void)hipFree(c->d_blk_d); (void)hipFree(c->d_blk_s); (void)hipFree(c->d_hist); (void)hipFree(c->d_chunk);
+    (void)hipFree(c->d_hist); (void)hipFree(c->d_chunk);
     (void)hipFree(c->d_long); (void)hipFree(c->d_dup);
-    c->d_blk_d = c->d_blk_s = c->d_hist = c->d_chunk = c->d_long = nullptr; c->d_dup = nullptr;
+    c->d_hist = c->d_chunk = c->d_long = nullptr; c->d_dup = nullptr;
     c->cap = 0;
 }
 
@@ -559,8 +598,6 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
         rc |= dalloc(&c->d_k1[i], half); rc |= dalloc(&c->d_k2[i], half); rc |= dalloc(&c->d_prec[i], half);
         rc |= dalloc(&c->d_sk1[i], n); rc |= dalloc(&c->d_srec[i], n);
     }
-    const size_t n_blocks = (n + kBuildBlock - 1) / kBuildBlock + 1;
-    rc |= dalloc(&c->d_blk_d, n_blocks); rc |= dalloc(&c->d_blk_s, n_blocks);
     rc |= dalloc(&c->d_hist, n_tiles * 256);
     rc |= dalloc(&c->d_chunk, ((n_tiles + kChunkTiles - 1) / kChunkTiles + 1) * 256);
     rc |= dalloc(&c->d_long, n / kWalkCap + 16);
@@ -585,7 +622,10 @@ int radix_sort(mgx_sortdedup* c, u64* key[2], u64* p64[2], u32* p32[2], u32 n, i
         hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, c->d_hist, n_tiles, c->d_chunk);
         const bool timing = c->ev_used + 2 <= c->ev_scatter.size();
         if (timing) HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used], s));
-        if (p64)
+        if (p64 && !p32)
+            hipLaunchKernelGGL((k_radix_scatter<true, false>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
+                               (const u32*)nullptr, (u32*)nullptr, n, shift, c->d_hist);
+        else if (p64)
             hipLaunchKernelGGL((k_radix_scatter<true, true>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
                                p32[in], p32[out], n, shift, c->d_hist);
         else if (p32)
@@ -659,7 +699,8 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
     int rc = ensure_capacity(c, (size_t)n_records);
     if (rc) { set_error("out of device memory for %llu records", (unsigned long long)n_records); return rc; }
     // double_pair_indicator: 4L bits like the reference (main.cpp:115)
-    const uint64_t bits = 4 * L + 64;
+    const uint64_t Lp = (L + kIndTile - 1) / kIndTile * kIndTile;          // tile-aligned reverse offset
+    const uint64_t bits = std::max<uint64_t>(4 * L + 64, 2 * Lp + 2 * (uint64_t)kIndTile);
     const size_t words = (size_t)((bits + 31) / 32);
     if (words > c->indicator_cap_words) {
         (void)hipFree(c->d_indicator); c->d_indicator = nullptr; c->indicator_cap_words = 0;
@@ -669,6 +710,7 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
     c->indicator_bits = 4 * L;
     c->L = L; c->n = (u32)n_records; c->ran = false;
     c->packed_coord = L < 0xFFFFFFFFull;     // coord <= L (bam_record.cpp:18-24)
+    c->packed_pair = L < 0xF0000000ull;      // 5' ends <= L + clip; verified against the device maximum
     // records are streamed through two pinned staging buffers on the copy stream
     const size_t total = (size_t)n_records * sizeof(mgx_rec_t);
     size_t off = 0;
@@ -698,13 +740,10 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         HIP_TRY(hipMemsetAsync(c->d_sc, 0, sizeof(Scalars), s));
         if (n) {
             HIP_TRY(hipMemsetAsync(c->d_dup, 0, n, s));
-            HIP_TRY(hipMemsetAsync(c->d_indicator, 0, (size_t)((c->indicator_bits + 64 + 31) / 32) * 4, s));
             const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
-            hipLaunchKernelGGL(k_build_count, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s);
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, c->d_blk_d, c->d_blk_s, nb, c->d_sc);
             BuildOut o{c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
-                       c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0};
-            hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, c->d_blk_d, c->d_blk_s, o, c->d_sc);
+                       c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0, c->packed_pair ? 1 : 0};
+            hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, o, c->d_sc);
             HIP_TRY(hipGetLastError());
         }
         // the only host round trip: entry counts and key maxima size the sorts
@@ -712,7 +751,11 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         HIP_TRY(hipStreamSynchronize(s));
         // a coordinate beyond L (a position past the end of its contig) does not fit the packed
         // (coord << 32 | index) key: rebuild once with separate key/value arrays
-        if (c->packed_coord && c->sc.max_coord >= (1ull << 32)) { c->packed_coord = false; continue; }
+        if ((c->packed_coord && c->sc.max_coord >= (1ull << 32)) || (c->packed_pair && c->sc.max_k2d >= (1ull << 32))) {
+            if (c->sc.max_coord >= (1ull << 32)) c->packed_coord = false;
+            if (c->sc.max_k2d >= (1ull << 32)) c->packed_pair = false;
+            continue;
+        }
         break;
     }
     const u32 nd = c->sc.n_double, ns = c->sc.n_single;
@@ -721,28 +764,63 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     c->stats.key_bits_pair1 = bits_of(std::max<uint64_t>(c->sc.max_k1d, c->sc.max_k1s));
     c->stats.key_bits_pair2 = bits_of(c->sc.max_k2d);
     int rc;
-    // doubles: LSD over (sort_key, mate 5' end): sort by the mate end first, then by sort_key
+    // indicator bitmap: tiled (plain stores, reverse half at a tile-aligned offset) whenever every 5' end
+    // is safely below L; otherwise the reference's exact layout with global atomics
+    const uint64_t maxpos = std::max<uint64_t>(c->sc.max_k2d, std::max<uint64_t>(c->sc.max_k1d >> 2, c->sc.max_k1s >> 2));
+    const bool tiled = c->L > 64 && maxpos < c->L - 64;
+    const uint64_t Lp = (c->L + kIndTile - 1) / kIndTile * kIndTile;
+    const uint64_t ind_off = tiled ? Lp : c->L;                 // offset of the reverse-strand half
+    const uint64_t ind_bits = tiled ? 2 * Lp : c->indicator_bits;
+    const u32 n_ind_tiles = (u32)((c->L + kIndTile - 1) / kIndTile);
+    if (!tiled && n) HIP_TRY(hipMemsetAsync(c->d_indicator, 0, (size_t)((c->indicator_bits + 64 + 31) / 32) * 4, s));
+
+    // doubles: LSD over (sort_key, mate 5' end): sort by the mate end first, then by sort_key.
+    // Packed form: two 8-byte arrays per entry -- sort_key and (mate end << 32 | record) -- take
+    // turns as key and payload (16 B per entry per pass, two LDS exchange rounds instead of three).
     int cur = 0;
-    if ((rc = radix_sort(c, c->d_k2, c->d_k1, c->d_prec, nd, 0, bits_of(c->sc.max_k2d), &cur))) return rc;
-    if (nd) hipLaunchKernelGGL(k_set_indicator<2>, dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd,
-                               c->d_indicator, c->indicator_bits, c->L);
-    if ((rc = radix_sort(c, c->d_k1, c->d_k2, c->d_prec, nd, 0, bits_of(c->sc.max_k1d), &cur))) return rc;
+    const bool pk = c->packed_pair;
+    if (pk) {
+        if ((rc = radix_sort(c, c->d_k2, c->d_k1, nullptr, nd, 32, bits_of(c->sc.max_k2d), &cur))) return rc;
+    } else {
+        if ((rc = radix_sort(c, c->d_k2, c->d_k1, c->d_prec, nd, 0, bits_of(c->sc.max_k2d), &cur))) return rc;
+    }
+    if (tiled && n) {
+        if (pk) hipLaunchKernelGGL((k_indicator_tiles<2, true>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+        else    hipLaunchKernelGGL((k_indicator_tiles<2, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+    } else if (nd) {
+        if (pk) hipLaunchKernelGGL((k_set_indicator<2, true>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
+        else    hipLaunchKernelGGL((k_set_indicator<2, false>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
+    }
+    if ((rc = radix_sort(c, c->d_k1, c->d_k2, pk ? nullptr : c->d_prec, nd, 0, bits_of(c->sc.max_k1d), &cur))) return rc;
     if (nd) {
-        hipLaunchKernelGGL(k_set_indicator<1>, dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd,
-                           c->d_indicator, c->indicator_bits, c->L);
-        hipLaunchKernelGGL(k_mark_runs<true>, dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
-                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_d);
-        hipLaunchKernelGGL(k_mark_long<true>, dim3(c->n_cu * 2), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
-                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+        const dim3 g((nd + 255) / 256), gl(c->n_cu * 2);
+        if (tiled) {
+            if (pk) hipLaunchKernelGGL((k_indicator_tiles<1, true>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+            else    hipLaunchKernelGGL((k_indicator_tiles<1, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+        } else {
+            if (pk) hipLaunchKernelGGL((k_set_indicator<1, true>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
+            else    hipLaunchKernelGGL((k_set_indicator<1, false>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
+        }
+        if (pk) {
+            hipLaunchKernelGGL((k_mark_runs<true, true>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], (const u32*)nullptr, nd,
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+            hipLaunchKernelGGL((k_mark_long<true, true>), gl, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], (const u32*)nullptr, nd,
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+        } else {
+            hipLaunchKernelGGL((k_mark_runs<true, false>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+            hipLaunchKernelGGL((k_mark_long<true, false>), gl, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+        }
     }
     // singles
     int scur = 0;
     if ((rc = radix_sort(c, c->d_sk1, nullptr, c->d_srec, ns, 0, bits_of(c->sc.max_k1s), &scur))) return rc;
     if (ns) {
-        hipLaunchKernelGGL(k_mark_runs<false>, dim3((ns + 255) / 256), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
-                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_s);
-        hipLaunchKernelGGL(k_mark_long<false>, dim3(c->n_cu * 2), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
-                           c->d_recs, c->d_indicator, c->indicator_bits, c->L, c->d_dup, c->d_long, &c->d_sc->n_long_s);
+        hipLaunchKernelGGL((k_mark_runs<false, false>), dim3((ns + 255) / 256), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_s);
+        hipLaunchKernelGGL((k_mark_long<false, false>), dim3(c->n_cu * 2), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_s);
     }
     // records by unified coordinate (stable: equal coordinates keep arrival order)
     int ccur = 0;

@@ -97,3 +97,27 @@ def test_scaled_config_properties(sd_engine, sd_oracle, synth):
 def test_empty_input(sd_engine, synth):
     order, dup = sd_engine.sort_mark(1000, np.zeros(0, dtype=synth.REC_DTYPE))
     assert len(order) == 0 and len(dup) == 0
+
+
+def test_wide_keys_take_the_unpacked_path(sd_engine, sd_oracle, synth):
+    """L >= 2^32: coordinates and 5' ends need more than 32 bits, so neither the packed coordinate
+    word nor the packed (mate end, record) word can be used."""
+    recs, L = synth.gen_sortdedup_packed(300_000, 8, n_contigs=30, contig_len=200_000_000)
+    assert L > (1 << 32)
+    want_order, want_dup, _ = sd_oracle.run(L, recs)
+    order, dup = sd_engine.sort_mark(L, recs)
+    assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
+    assert sd_engine.stats()["key_bits_coord"] > 32
+
+
+def test_wrapped_five_prime_forces_the_fallback(sd_engine, sd_oracle, synth):
+    """A forward read whose leading soft clip is longer than its position has a 5' end below zero;
+    the reference keeps it as a wrapped uint64 (bam_record.cpp:36-44).  Packed 32-bit fields cannot
+    hold it, the pipeline must notice and rebuild with wide keys."""
+    recs, L = synth.gen_sortdedup_packed(100_000, 9, n_contigs=3, contig_len=1_000_000)
+    recs = recs.copy()
+    recs["prime5"][10] = np.uint64(2**64 - 5)          # record 10 and its mate form a pair
+    recs["prime5"][501] = np.uint64(2**64 - 7)
+    want_order, want_dup, _ = sd_oracle.run(L, recs)
+    order, dup = sd_engine.sort_mark(L, recs)
+    assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
