@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgx.so")
 SOURCES = ["mgx_common.cpp", "mgx_tables.cpp", "sortdedup_pack.cpp", "mgx_pairhmm.hip", "mgx_sortdedup.hip"]
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -114,16 +114,14 @@ public:
             read_off.push_back(bases.size());
         }
         const int n_unique = (int)read_off.size() - 1;
-        // ---- one test case per (unique read, haplotype), read-major like uniqueTestcases
-        std::vector<uint32_t> pair_read((size_t)n_unique * n_haps), pair_hap((size_t)n_unique * n_haps);
-        for (int u = 0; u < n_unique; ++u)
-            for (int h = 0; h < n_haps; ++h) { pair_read[(size_t)u * n_haps + h] = u; pair_hap[(size_t)u * n_haps + h] = h; }
+        // ---- one test case per (unique read, haplotype), read-major like uniqueTestcases: the
+        //      cross-product form of the ABI (pair arrays NULL), out[u * n_haps + h]
         mgx_pairhmm_input_t in{};
         in.n_reads = n_unique; in.read_off = read_off.data();
         in.bases = bases.data(); in.qual = qual.data(); in.ins = ins.data(); in.del = del.data(); in.gcp = gc.data();
         in.n_haps = n_haps; in.hap_off = hap_off_.data(); in.hap_bases = hap_bases_.data();
-        in.n_pairs = pair_read.size(); in.pair_read = pair_read.data(); in.pair_hap = pair_hap.data();
-        std::vector<double> out(pair_read.size());
+        in.n_pairs = (uint64_t)n_unique * n_haps; in.pair_read = nullptr; in.pair_hap = nullptr;
+        std::vector<double> out((size_t)n_unique * n_haps);
         if (mgx_pairhmm_compute(ctx_, &in, out.data()) != 0)
             throw std::runtime_error(std::string("mgx_pairhmm_compute: ") + mgx_last_error());
         // ---- scatter (VectorLoglessPairHMM.cpp:135-146)

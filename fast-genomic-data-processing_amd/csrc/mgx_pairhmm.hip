@@ -41,6 +41,18 @@ struct Bin {
 
 }  // namespace
 
+namespace {
+// One device allocation + (for batches up to kStageLimit) a pinned host mirror of the same size.
+// Slabs are recycled through the context, so a stream of region-sized batches does no hipMalloc.
+struct Slab {
+    uint8_t* dev = nullptr;
+    uint8_t* pin = nullptr;
+    size_t cap = 0;
+};
+constexpr size_t kStageLimit = 256u << 20;
+constexpr size_t kMinSlab = 1u << 20;
+}  // namespace
+
 struct mgx_pairhmm {
     int device = 0;
     unsigned flags = 0;
@@ -49,18 +61,25 @@ struct mgx_pairhmm {
     double* d_ph2pr_d = nullptr; double* d_mm_d = nullptr;
     float log10_initial_f = 0; double log10_initial_d = 0;
     int n_cu = 256;
+    std::vector<Slab> free_slabs;
 };
 
 struct mgx_pairhmm_batch {
     uint64_t n_pairs = 0;
     std::vector<Bin> bins;
-    // device buffers
+    // everything lives in one slab: [jobs | bases | qual | ins | del | gcp | hap] is written once
+    // (one H2D copy when staged through the pinned mirror), [out | used] is read back with one
+    // D2H copy, [rerun_list | rerun_count] is device scratch
+    Slab slab;
+    size_t in_bytes = 0, o_out = 0, o_used = 0, result_bytes = 0;
     uint8_t *d_bases = nullptr, *d_qual = nullptr, *d_ins = nullptr, *d_del = nullptr,
             *d_gcp = nullptr, *d_hap = nullptr, *d_used = nullptr;
     Job* d_jobs = nullptr;
     uint32_t* d_rerun_list = nullptr;
     uint32_t* d_rerun_count = nullptr;
     double* d_out = nullptr;
+    std::vector<Job> host_jobs;    // only kept for unstaged (very large) batches
+    hipEvent_t uploaded = nullptr;
     // timing
     std::vector<hipEvent_t> ev;    // 4 per bin: f32 start/stop, f64 start/stop
     bool ran = false;
@@ -101,12 +120,70 @@ inline uint32_t lds_bytes(const Bin& bin, bool f32) {
     return waves * etab + groups * bin.lds_stride;
 }
 inline int bin_index(int G, int RPL) { return (G == 16 ? 0 : 8) + RPL - 1; }
+constexpr int kBins = 16;
+constexpr uint64_t kMergeBelow = 4096;
+
+// launch geometry of a bin once job_count and max_h are known
+int finalize_bin(Bin& bin, int n_cu) {
+    // LDS per group: G pad + codes + G pad + prefetch slack (see the kernel's staging loop)
+    bin.lds_stride = (bin.max_h + 2u * (uint32_t)bin.G + 8u + 15u) & ~15u;
+    bin.block = 128;                  // 2 wavefronts: fine-grained LDS/VGPR packing per CU
+    while (bin.block > 64u && lds_bytes(bin, true) > kMaxLdsPerBlock) bin.block /= 2;
+    if (lds_bytes(bin, true) > 160u * 1024u) {
+        set_error("haplotype of %u bases does not fit the LDS staging buffer", bin.max_h);
+        return -E2BIG;
+    }
+    const uint32_t gpb = bin.block / bin.G;
+    bin.grid_f32 = (bin.job_count + gpb - 1) / gpb;
+    bin.grid_f64 = std::min<uint32_t>(bin.grid_f32, (uint32_t)n_cu * 8u);
+    return 0;
+}
+// fold sparsely populated bins into the next larger row class of the same group width
+void merge_small_bins(uint64_t (&count)[kBins], int (&remap)[kBins]) {
+    for (int k = 0; k < kBins; ++k) remap[k] = k;
+    for (int base = 0; base < kBins; base += 8)
+        for (int k = base; k < base + 7; ++k)
+            if (count[k] && count[k] < kMergeBelow) { count[k + 1] += count[k]; count[k] = 0; remap[k] = k + 1; }
+    for (int k = 0; k < kBins; ++k) { int t = k; while (remap[t] != t) t = remap[t]; remap[k] = t; }
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+int acquire_slab(mgx_pairhmm* c, size_t bytes, bool want_pinned, Slab* out) {
+    int best = -1;
+    for (size_t i = 0; i < c->free_slabs.size(); ++i) {
+        const Slab& f = c->free_slabs[i];
+        if (f.cap >= bytes && (!want_pinned || f.pin) && (best < 0 || f.cap < c->free_slabs[best].cap)) best = (int)i;
+    }
+    if (best >= 0) { *out = c->free_slabs[best]; c->free_slabs.erase(c->free_slabs.begin() + best); return 0; }
+    size_t cap = kMinSlab;
+    while (cap < bytes) cap *= 2;
+    if (cap > bytes + (bytes >> 2) && bytes > (64u << 20)) cap = align_up(bytes, 1u << 20);   // no 2x waste on big batches
+    Slab sl;
+    sl.cap = cap;
+    HIP_TRY(hipMalloc((void**)&sl.dev, cap));
+    if (want_pinned) {
+        if (hipHostMalloc((void**)&sl.pin, cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(sl.dev);
+            set_error("hipHostMalloc of %zu bytes failed", cap);
+            return -ENOMEM;
+        }
+    }
+    *out = sl;
+    return 0;
+}
+void release_slab(mgx_pairhmm* c, Slab sl) {
+    if (!sl.dev) return;
+    if (c && c->free_slabs.size() < 16) { c->free_slabs.push_back(sl); return; }
+    (void)hipFree(sl.dev);
+    if (sl.pin) (void)hipHostFree(sl.pin);
+}
 
 int validate(const mgx_pairhmm_input_t* in) {
     if (!in) { set_error("input is NULL"); return -EINVAL; }
-    if (in->n_pairs == 0) return 0;
+    if (in->n_pairs == 0 && (in->pair_read || in->n_reads == 0 || in->n_haps == 0)) return 0;
     if (!in->read_off || !in->hap_off || !in->bases || !in->qual || !in->ins || !in->del ||
-        !in->gcp || !in->hap_bases || !in->pair_read || !in->pair_hap) {
+        !in->gcp || !in->hap_bases || (!in->pair_read != !in->pair_hap)) {
         set_error("a required input array is NULL");
         return -EINVAL;
     }
@@ -169,6 +246,7 @@ void mgx_pairhmm_destroy(mgx_pairhmm_t* c) {
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_ph2pr_f); (void)hipFree(c->d_mm_f);
     (void)hipFree(c->d_ph2pr_d); (void)hipFree(c->d_mm_d);
+    for (auto& sl : c->free_slabs) { (void)hipFree(sl.dev); if (sl.pin) (void)hipHostFree(sl.pin); }
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
     delete c;
@@ -176,14 +254,121 @@ void mgx_pairhmm_destroy(mgx_pairhmm_t* c) {
 
 void mgx_pairhmm_batch_destroy(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     if (!b) return;
-    if (c) (void)hipSetDevice(c->device);
-    (void)hipFree(b->d_bases); (void)hipFree(b->d_qual); (void)hipFree(b->d_ins);
-    (void)hipFree(b->d_del); (void)hipFree(b->d_gcp); (void)hipFree(b->d_hap);
-    (void)hipFree(b->d_used); (void)hipFree(b->d_jobs); (void)hipFree(b->d_rerun_list);
-    (void)hipFree(b->d_rerun_count); (void)hipFree(b->d_out);
+    if (c) {
+        (void)hipSetDevice(c->device);
+        // the slab goes back to the pool: nothing may still be reading or writing it
+        (void)hipStreamSynchronize(c->copy);
+        (void)hipStreamSynchronize(c->compute);
+    }
+    release_slab(c, b->slab);
+    if (b->uploaded) (void)hipEventDestroy(b->uploaded);
     for (auto e : b->ev) (void)hipEventDestroy(e);
     delete b;
 }
+
+namespace {
+
+// Batch of every read against every haplotype (pair_read == pair_hap == NULL):
+// out[r * n_haps + h].  Host work is O(n_reads + n_haps); job descriptors are made on the device.
+int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_batch* b) {
+    const uint64_t nr = in->n_reads, nh = in->n_haps;
+    const uint64_t n = nr * nh;
+    if (n > 0xFFFFFFF0ull) { set_error("more than 2^32 test cases in one batch"); return -E2BIG; }
+    b->n_pairs = n;
+    b->stats.n_pairs = n;
+    int rc;
+    uint64_t count[kBins] = {0};
+    std::vector<uint8_t> rbin(nr);
+    uint64_t sumR_bin[kBins] = {0}, sumH = 0;
+    uint32_t max_h = 0;
+    for (uint64_t r = 0; r < nr; ++r) {
+        const uint64_t R = in->read_off[r + 1] - in->read_off[r];
+        if (R == 0) { set_error("read %llu is empty", (unsigned long long)r); return -EINVAL; }
+        int G, RPL;
+        shape_of((uint32_t)std::min<uint64_t>(R, 0xFFFFFFFFull), &G, &RPL);
+        if (G == 0) { set_error("read %llu: read of %llu bases exceeds the %d-row limit", (unsigned long long)r, (unsigned long long)R, kMaxRowsG64); return -E2BIG; }
+        rbin[r] = (uint8_t)bin_index(G, RPL);
+        count[rbin[r]] += nh;
+    }
+    std::vector<SeqRef> haps(nh);
+    for (uint64_t h = 0; h < nh; ++h) {
+        const uint64_t H = in->hap_off[h + 1] - in->hap_off[h];
+        if (H == 0) { set_error("haplotype %llu is empty", (unsigned long long)h); return -EINVAL; }
+        if (H > 0x7FFFFFF0ull) { set_error("haplotype too long"); return -E2BIG; }
+        haps[h] = SeqRef{in->hap_off[h], (uint32_t)H, (uint32_t)h};
+        sumH += H; max_h = std::max<uint32_t>(max_h, (uint32_t)H);
+    }
+    std::stable_sort(haps.begin(), haps.end(), [](const SeqRef& a, const SeqRef& b2) { return a.len < b2.len; });
+    int remap[kBins];
+    merge_small_bins(count, remap);
+    uint64_t reads_in[kBins] = {0}, rstart[kBins + 1] = {0};
+    for (uint64_t r = 0; r < nr; ++r) { rbin[r] = (uint8_t)remap[rbin[r]]; reads_in[rbin[r]]++; sumR_bin[rbin[r]] += in->read_off[r + 1] - in->read_off[r]; }
+    for (int k = 0; k < kBins; ++k) rstart[k + 1] = rstart[k] + reads_in[k];
+    // slab layout
+    const uint64_t read_bytes = in->read_off[nr], hap_bytes = in->hap_off[nh];
+    size_t off = 0;
+    const size_t o_rtab = off;  off = align_up(off + nr * sizeof(SeqRef));
+    const size_t o_htab = off;  off = align_up(off + nh * sizeof(SeqRef));
+    const size_t o_bases = off; off = align_up(off + read_bytes);
+    const size_t o_qual = off;  off = align_up(off + read_bytes);
+    const size_t o_ins = off;   off = align_up(off + read_bytes);
+    const size_t o_del = off;   off = align_up(off + read_bytes);
+    const size_t o_gcp = off;   off = align_up(off + read_bytes);
+    const size_t o_hap = off;   off = align_up(off + hap_bytes);
+    b->in_bytes = off;
+    const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
+    b->o_out = off;             off = align_up(off + n * sizeof(double));
+    b->o_used = off;            off = align_up(off + n);
+    b->result_bytes = off - b->o_out;
+    const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
+    const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
+    // the pinned mirror only has to cover the inputs and the results
+    if ((rc = acquire_slab(c, off, true, &b->slab))) return rc;
+    uint8_t* dv = b->slab.dev; uint8_t* pin = b->slab.pin;
+    b->d_jobs = (Job*)(dv + o_jobs);
+    b->d_bases = dv + o_bases; b->d_qual = dv + o_qual; b->d_ins = dv + o_ins; b->d_del = dv + o_del;
+    b->d_gcp = dv + o_gcp; b->d_hap = dv + o_hap;
+    b->d_out = (double*)(dv + b->o_out); b->d_used = dv + b->o_used;
+    b->d_rerun_list = (uint32_t*)(dv + o_rlist); b->d_rerun_count = (uint32_t*)(dv + o_rcount);
+    SeqRef* rtab = (SeqRef*)(pin + o_rtab);
+    {
+        uint64_t cur[kBins];
+        for (int k = 0; k < kBins; ++k) cur[k] = rstart[k];
+        for (uint64_t r = 0; r < nr; ++r)
+            rtab[cur[rbin[r]]++] = SeqRef{in->read_off[r], (uint32_t)(in->read_off[r + 1] - in->read_off[r]), (uint32_t)r};
+    }
+    memcpy(pin + o_htab, haps.data(), nh * sizeof(SeqRef));
+    memcpy(pin + o_bases, in->bases, read_bytes); memcpy(pin + o_qual, in->qual, read_bytes);
+    memcpy(pin + o_ins, in->ins, read_bytes);     memcpy(pin + o_del, in->del, read_bytes);
+    memcpy(pin + o_gcp, in->gcp, read_bytes);     memcpy(pin + o_hap, in->hap_bases, hap_bytes);
+    hipStream_t s = c->copy;
+    HIP_TRY(hipMemcpyAsync(dv, pin, b->in_bytes, hipMemcpyHostToDevice, s));
+    uint64_t job_begin = 0;
+    for (int k = 0; k < kBins; ++k) {
+        if (!reads_in[k]) continue;
+        Bin bin;
+        bin.G = k < 8 ? 16 : 64;
+        bin.RPL = (k % 8) + 1;
+        bin.job_begin = (uint32_t)job_begin;
+        bin.job_count = (uint32_t)(reads_in[k] * nh);
+        bin.max_h = max_h;
+        bin.cells = sumR_bin[k] * sumH;
+        bin.alg_bytes = 5 * sumR_bin[k] * nh + reads_in[k] * (sumH + 4 * nh);
+        if ((rc = finalize_bin(bin, c->n_cu))) return rc;
+        hipLaunchKernelGGL(pairhmm_make_jobs, dim3((bin.job_count + 255) / 256), dim3(256), 0, s,
+                           (const SeqRef*)(dv + o_rtab) + rstart[k], (const SeqRef*)(dv + o_htab), (uint32_t)nh,
+                           bin.job_count, b->d_jobs + job_begin);
+        b->stats.cells += bin.cells; b->stats.alg_bytes += bin.alg_bytes;
+        b->bins.push_back(bin);
+        job_begin += bin.job_count;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->uploaded, s));
+    return 0;
+}
+
+}  // namespace
 
 int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
                              mgx_pairhmm_batch_t** out) {
@@ -194,13 +379,22 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
     HIP_TRY(hipSetDevice(c->device));
     std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
         new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+    // (on an error path the slab is freed, not pooled: destroy is called without the context)
     if (!b) return -ENOMEM;
+    if (!in->pair_read && !in->pair_hap && in->n_reads && in->n_haps) {      // cross-product form
+        if ((rc = create_cross(c, in, b.get()))) return rc;
+        if (c->flags & MGX_PAIRHMM_TIMING) {
+            b->ev.resize(b->bins.size() * 4);
+            for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+        }
+        *out = b.release();
+        return 0;
+    }
     const uint64_t n = in->n_pairs;
     b->n_pairs = n;
     b->stats.n_pairs = n;
 
     // ---- bin by (G, RPL), then counting-sort every bin by haplotype length -------------
-    constexpr int kBins = 16;
     std::vector<uint32_t> bin_of(n);
     uint64_t count[kBins] = {0};
     uint32_t max_h = 0;
@@ -221,7 +415,42 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
         b->stats.cells += R * H;
         b->stats.alg_bytes += 5 * R + H + 4;
     }
-    std::vector<Job> jobs(n);
+    // A bin with few jobs is folded into the next larger row class of the same group width (any
+    // RPL >= ceil(R/G) is valid, it only leaves lanes unused): a region-sized batch then needs one
+    // fp32 + one fp64 launch instead of one pair per read-length class.
+    {
+        int remap[kBins];
+        merge_small_bins(count, remap);
+        for (uint64_t i = 0; i < n; ++i) bin_of[i] = (uint32_t)remap[bin_of[i]];
+    }
+    // ---- one slab for everything; layout decided before the jobs are written so that they can be
+    //      built directly in the pinned mirror
+    const uint64_t read_bytes = in->read_off[in->n_reads];
+    const uint64_t hap_bytes = in->hap_off[in->n_haps];
+    size_t off = 0;
+    const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
+    const size_t o_bases = off; off = align_up(off + read_bytes);
+    const size_t o_qual = off;  off = align_up(off + read_bytes);
+    const size_t o_ins = off;   off = align_up(off + read_bytes);
+    const size_t o_del = off;   off = align_up(off + read_bytes);
+    const size_t o_gcp = off;   off = align_up(off + read_bytes);
+    const size_t o_hap = off;   off = align_up(off + hap_bytes);
+    b->in_bytes = off;
+    b->o_out = off;             off = align_up(off + n * sizeof(double));
+    b->o_used = off;            off = align_up(off + n);
+    b->result_bytes = off - b->o_out;
+    const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
+    const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
+    const bool staged = off <= kStageLimit;
+    if ((rc = acquire_slab(c, off, staged, &b->slab))) return rc;
+    uint8_t* dv = b->slab.dev;
+    b->d_jobs = (Job*)(dv + o_jobs);
+    b->d_bases = dv + o_bases; b->d_qual = dv + o_qual; b->d_ins = dv + o_ins; b->d_del = dv + o_del;
+    b->d_gcp = dv + o_gcp; b->d_hap = dv + o_hap;
+    b->d_out = (double*)(dv + b->o_out); b->d_used = dv + b->o_used;
+    b->d_rerun_list = (uint32_t*)(dv + o_rlist); b->d_rerun_count = (uint32_t*)(dv + o_rcount);
+    if (!staged) b->host_jobs.resize(n);
+    Job* jobs = staged ? (Job*)(b->slab.pin + o_jobs) : b->host_jobs.data();
     {
         // key = (bin, H): counting sort on H inside each bin keeps the wavefront's groups
         // (consecutive jobs) at near-equal step counts.
@@ -257,37 +486,32 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
                 bin.cells += (uint64_t)jobs[q].R * jobs[q].H;
                 bin.alg_bytes += 5ull * jobs[q].R + jobs[q].H + 4;
             }
-            // LDS per group: G pad + codes + G pad + prefetch slack (see the kernel's staging loop)
-            bin.lds_stride = (bin.max_h + 2u * (uint32_t)bin.G + 8u + 15u) & ~15u;
-            bin.block = 128;                  // 2 wavefronts: fine-grained LDS/VGPR packing per CU
-            while (bin.block > 64u && lds_bytes(bin, true) > kMaxLdsPerBlock) bin.block /= 2;
-            if (lds_bytes(bin, true) > 160u * 1024u) {
-                set_error("haplotype of %u bases does not fit the LDS staging buffer", bin.max_h);
-                return -E2BIG;
-            }
-            const uint32_t gpb = bin.block / bin.G;
-            bin.grid_f32 = (bin.job_count + gpb - 1) / gpb;
-            bin.grid_f64 = std::min<uint32_t>(bin.grid_f32, (uint32_t)c->n_cu * 8u);
+            if ((rc = finalize_bin(bin, c->n_cu))) return rc;
             b->bins.push_back(bin);
         }
     }
 
-    // ---- upload ---------------------------------------------------------------------
-    const uint64_t read_bytes = in->read_off[in->n_reads];
-    const uint64_t hap_bytes = in->hap_off[in->n_haps];
+    // ---- upload: one copy out of the pinned mirror, or (very large batches) one per array
     hipStream_t s = c->copy;
-    if ((rc = upload(&b->d_bases, in->bases, read_bytes, s))) return rc;
-    if ((rc = upload(&b->d_qual, in->qual, read_bytes, s))) return rc;
-    if ((rc = upload(&b->d_ins, in->ins, read_bytes, s))) return rc;
-    if ((rc = upload(&b->d_del, in->del, read_bytes, s))) return rc;
-    if ((rc = upload(&b->d_gcp, in->gcp, read_bytes, s))) return rc;
-    if ((rc = upload(&b->d_hap, in->hap_bases, hap_bytes, s))) return rc;
-    if ((rc = upload(&b->d_jobs, jobs.data(), n * sizeof(Job), s))) return rc;
-    if ((rc = upload(&b->d_rerun_list, nullptr, n * sizeof(uint32_t), s))) return rc;
-    if ((rc = upload(&b->d_rerun_count, nullptr, 64 * sizeof(uint32_t), s))) return rc;
-    if ((rc = upload(&b->d_out, nullptr, n * sizeof(double), s))) return rc;
-    if ((rc = upload(&b->d_used, nullptr, n, s))) return rc;
-    HIP_TRY(hipStreamSynchronize(s));   // jobs vector goes out of scope; batch is now resident
+    if (staged) {
+        uint8_t* pin = b->slab.pin;
+        memcpy(pin + o_bases, in->bases, read_bytes); memcpy(pin + o_qual, in->qual, read_bytes);
+        memcpy(pin + o_ins, in->ins, read_bytes);     memcpy(pin + o_del, in->del, read_bytes);
+        memcpy(pin + o_gcp, in->gcp, read_bytes);     memcpy(pin + o_hap, in->hap_bases, hap_bytes);
+        HIP_TRY(hipMemcpyAsync(dv, pin, b->in_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(b->d_jobs, jobs, n * sizeof(Job), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->d_bases, in->bases, read_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->d_qual, in->qual, read_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->d_ins, in->ins, read_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->d_del, in->del, read_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->d_gcp, in->gcp, read_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->d_hap, in->hap_bases, hap_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));          // the caller's buffers may go away after we return
+        b->host_jobs.clear(); b->host_jobs.shrink_to_fit();
+    }
+    HIP_TRY(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->uploaded, s));       // batch_run makes the compute stream wait on this
     if (c->flags & MGX_PAIRHMM_TIMING) {
         b->ev.resize(b->bins.size() * 4);
         for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
@@ -303,6 +527,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     hipStream_t s = c->compute;
     const bool timing = (c->flags & MGX_PAIRHMM_TIMING) != 0;
     const bool force_f64 = (c->flags & MGX_PAIRHMM_FORCE_DOUBLE) != 0;
+    if (b->uploaded) HIP_TRY(hipStreamWaitEvent(s, b->uploaded, 0));
     HIP_TRY(hipMemsetAsync(b->d_rerun_count, 0, 64 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(b->d_used, 0, b->n_pairs, s));
     for (size_t k = 0; k < b->bins.size(); ++k) {
@@ -398,6 +623,15 @@ int mgx_pairhmm_batch_results(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, double* 
     HIP_TRY(hipSetDevice(c->device));
     if (b->n_pairs == 0) return 0;
     if (!out_log10) { set_error("out_log10 is NULL"); return -EINVAL; }
+    if (b->slab.pin) {
+        uint8_t* pin = b->slab.pin + b->o_out;
+        const size_t bytes = used_f64 ? b->result_bytes : b->n_pairs * sizeof(double);
+        HIP_TRY(hipMemcpyAsync(pin, b->d_out, bytes, hipMemcpyDeviceToHost, c->compute));
+        HIP_TRY(hipStreamSynchronize(c->compute));
+        memcpy(out_log10, pin, b->n_pairs * sizeof(double));
+        if (used_f64) memcpy(used_f64, b->slab.pin + b->o_used, b->n_pairs);
+        return 0;
+    }
     HIP_TRY(hipMemcpyAsync(out_log10, b->d_out, b->n_pairs * sizeof(double), hipMemcpyDeviceToHost, c->compute));
     if (used_f64) HIP_TRY(hipMemcpyAsync(used_f64, b->d_used, b->n_pairs, hipMemcpyDeviceToHost, c->compute));
     HIP_TRY(hipStreamSynchronize(c->compute));

@@ -29,21 +29,26 @@ def make_input(d):
         read_off=_as(d["read_off"], np.uint64), bases=_as(d["bases"], np.uint8),
         qual=_as(d["qual"], np.uint8), ins=_as(d["ins"], np.uint8), dele=_as(d["dele"], np.uint8),
         gcp=_as(d["gcp"], np.uint8), hap_off=_as(d["hap_off"], np.uint64),
-        hap_bases=_as(d["hap_bases"], np.uint8), pair_read=_as(d["pair_read"], np.uint32),
-        pair_hap=_as(d["pair_hap"], np.uint32))
+        hap_bases=_as(d["hap_bases"], np.uint8))
+    cross = d.get("pair_read") is None          # every read x every haplotype, read-major
+    if not cross:
+        keep["pair_read"] = _as(d["pair_read"], np.uint32)
+        keep["pair_hap"] = _as(d["pair_hap"], np.uint32)
+    n_reads, n_haps = len(keep["read_off"]) - 1, len(keep["hap_off"]) - 1
     inp = native.PairHMMInput(
         n_reads=len(keep["read_off"]) - 1, read_off=_ptr(keep["read_off"]), bases=_ptr(keep["bases"]),
         qual=_ptr(keep["qual"]), ins=_ptr(keep["ins"]), del_=_ptr(keep["dele"]), gcp=_ptr(keep["gcp"]),
         n_haps=len(keep["hap_off"]) - 1, hap_off=_ptr(keep["hap_off"]), hap_bases=_ptr(keep["hap_bases"]),
-        n_pairs=len(keep["pair_read"]), pair_read=_ptr(keep["pair_read"]), pair_hap=_ptr(keep["pair_hap"]))
+        n_pairs=n_reads * n_haps if cross else len(keep["pair_read"]),
+        pair_read=None if cross else _ptr(keep["pair_read"]), pair_hap=None if cross else _ptr(keep["pair_hap"]))
     return inp, keep
 
 
 class PairHMMBatch:
     def __init__(self, engine, d):
         self.engine = engine
-        self.n_pairs = len(d["pair_read"])
         inp, keep = make_input(d)
+        self.n_pairs = int(inp.n_pairs)
         h = C.c_void_p()
         native.check(engine.lib.mgx_pairhmm_batch_create(engine.ctx, C.byref(inp), C.byref(h)))
         self.h = h

@@ -62,6 +62,10 @@ typedef struct mgx_pairhmm_input {
     uint64_t n_pairs;
     const uint32_t* pair_read; /* [n_pairs] read index of test case i */
     const uint32_t* pair_hap;  /* [n_pairs] haplotype index of test case i */
+    /* Cross-product form: pair_read == pair_hap == NULL means "every read against every
+     * haplotype", n_reads * n_haps test cases with out_log10[r * n_haps + h] -- the list
+     * VectorLoglessPairHMM builds for a region (VectorLoglessPairHMM.cpp:88-93); n_pairs is then
+     * ignored, host work is O(n_reads + n_haps) and the job list is generated on the device. */
 } mgx_pairhmm_input_t;
 
 typedef struct mgx_pairhmm_stats {

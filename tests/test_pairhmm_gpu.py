@@ -109,3 +109,31 @@ def test_empty_batch(engine):
     e["pair_read"] = np.zeros(0, dtype=np.uint32)
     e["pair_hap"] = np.zeros(0, dtype=np.uint32)
     assert engine.compute(e).shape == (0,)
+
+
+def test_cross_product_form_equals_explicit_pairs(engine, oracle, synth):
+    """pair_read == pair_hap == NULL: every read x every haplotype, jobs generated on the device."""
+    for (nr, nh, seed, rr) in [(40, 25, 1, (20, 128)), (7, 3, 2, (1, 16)), (200, 64, 3, (60, 128)), (33, 10, 4, (100, 300))]:
+        d = synth.gen_pairhmm_region(nr, nh, seed, r_range=rr, h_range=(50, 256))
+        explicit = engine.compute(d)
+        cross = dict(d)
+        cross["pair_read"] = None
+        cross["pair_hap"] = None
+        got = engine.compute(cross)
+        assert got.shape == (nr * nh,)
+        assert np.array_equal(got, explicit)
+        want, _ = oracle.batch(d)
+        assert_log10_close(got, want)
+
+
+def test_result_does_not_depend_on_batch_composition(engine, synth):
+    """A test case must give the same bits whatever else is in the batch (different wavefront
+    neighbours change how many columns run in the unguarded loop versus the guarded tail)."""
+    d = synth.gen_pairhmm_pairs(6000, 77, r_range=(30, 128), h_range=(20, 256))
+    full = engine.compute(d)
+    rng = np.random.RandomState(0)
+    for trial in range(3):
+        idx = np.sort(rng.choice(6000, 1500, replace=False))
+        sub = dict(d)
+        sub["pair_read"], sub["pair_hap"] = d["pair_read"][idx], d["pair_hap"][idx]
+        assert np.array_equal(engine.compute(sub), full[idx])
