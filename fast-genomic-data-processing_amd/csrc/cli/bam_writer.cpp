@@ -1,0 +1,236 @@
+// bam_writer.cpp -- see bam_writer.h.  Formats follow SAMv1 sections 4.1 (BGZF), 4.2 (BAM), 5.2 (BAI).
+#include "bam_writer.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <thread>
+
+namespace bamout {
+
+namespace {
+
+constexpr size_t kBlockIn = 0xff00;          // uncompressed bytes per BGZF block
+constexpr size_t kBgzfHeader = 18, kBgzfFooter = 8;
+
+template <typename T>
+inline void put(std::vector<uint8_t>& a, T v) { const uint8_t* p = (const uint8_t*)&v; a.insert(a.end(), p, p + sizeof(T)); }
+
+// one BGZF block for in[0, n); appended to out.  level 0..9
+bool bgzf_block(const uint8_t* in, size_t n, int level, std::vector<uint8_t>* out) {
+    uint8_t buf[65536];
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, attempt == 0 ? level : 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        zs.next_in = const_cast<uint8_t*>(in); zs.avail_in = (uInt)n;
+        zs.next_out = buf + kBgzfHeader; zs.avail_out = (uInt)(sizeof buf - kBgzfHeader - kBgzfFooter);
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) continue;      // did not fit: retry stored (always fits for n <= 0xff00)
+        const size_t total = kBgzfHeader + clen + kBgzfFooter;
+        static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(buf, head, 16);
+        const uint16_t bsize = (uint16_t)(total - 1);
+        memcpy(buf + 16, &bsize, 2);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n), isize = (uint32_t)n;
+        memcpy(buf + kBgzfHeader + clen, &crc, 4);
+        memcpy(buf + kBgzfHeader + clen + 4, &isize, 4);
+        out->insert(out->end(), buf, buf + total);
+        return true;
+    }
+    return false;
+}
+
+struct Slice {                       // output of one writer thread
+    std::vector<uint8_t> bytes;      // compressed
+    std::vector<uint64_t> vbeg, vend;   // per record: (compressed offset within slice) << 16 | offset in block
+    bool ok = true;
+};
+
+void compress_slice(const std::vector<RecordRef>& recs, size_t lo, size_t hi, int level, Slice* s) {
+    std::vector<uint8_t> block;
+    block.reserve(kBlockIn + 1024);
+    s->vbeg.resize(hi - lo); s->vend.resize(hi - lo);
+    auto flush = [&]() {
+        if (block.empty()) return;
+        if (!bgzf_block(block.data(), block.size(), level, &s->bytes)) s->ok = false;
+        block.clear();
+    };
+    for (size_t k = lo; k < hi; ++k) {
+        const RecordRef& r = recs[k];
+        const size_t need = 4 + (size_t)r.len;
+        if (!block.empty() && block.size() + need > kBlockIn) flush();
+        s->vbeg[k - lo] = ((uint64_t)s->bytes.size() << 16) | (uint64_t)block.size();
+        const uint32_t bs = r.len;
+        put<uint32_t>(block, bs);
+        const size_t at = block.size();
+        block.insert(block.end(), r.blob, r.blob + r.len);
+        if (r.set_dup) { uint16_t f; memcpy(&f, &block[at + kFlagOffset], 2); f |= 0x400; memcpy(&block[at + kFlagOffset], &f, 2); }
+        // a record larger than one block spans several: cut greedily
+        while (block.size() > kBlockIn) {
+            std::vector<uint8_t> rest(block.begin() + kBlockIn, block.end());
+            block.resize(kBlockIn);
+            flush();
+            block = std::move(rest);
+        }
+        if (block.size() == kBlockIn) { flush(); }
+        s->vend[k - lo] = ((uint64_t)s->bytes.size() << 16) | (uint64_t)block.size();
+    }
+    flush();
+}
+
+inline uint64_t rebase(uint64_t v, uint64_t base) { return (((v >> 16) + base) << 16) | (v & 0xffff); }
+
+struct RefIndex {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> linear;
+    uint64_t off_beg = ~0ull, off_end = 0, n_mapped = 0, n_unmapped = 0;
+};
+
+}  // namespace
+
+int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+void encode_record(const samtext::Record& r, std::vector<uint8_t>* out) {
+    std::vector<uint8_t>& a = *out;
+    put<int32_t>(a, r.tid);
+    put<int32_t>(a, r.pos);
+    a.push_back((uint8_t)(r.qname.size() + 1));
+    a.push_back(r.mapq);
+    put<uint16_t>(a, (uint16_t)reg2bin(r.pos, r.end()));
+    put<uint16_t>(a, (uint16_t)r.cigar.size());
+    put<uint16_t>(a, r.flag);
+    put<int32_t>(a, (int32_t)r.l_seq);
+    put<int32_t>(a, r.mtid);
+    put<int32_t>(a, r.mpos);
+    put<int32_t>(a, r.tlen);
+    a.insert(a.end(), r.qname.begin(), r.qname.end());
+    a.push_back(0);
+    for (uint32_t c : r.cigar) put<uint32_t>(a, c);
+    a.insert(a.end(), r.seq4.begin(), r.seq4.end());
+    a.insert(a.end(), r.qual.begin(), r.qual.end());
+    a.insert(a.end(), r.aux.begin(), r.aux.end());
+}
+
+bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
+               int threads, int level, std::string* err) {
+    // ---- BAM header, in BGZF blocks of its own
+    std::vector<uint8_t> head;
+    head.insert(head.end(), {'B', 'A', 'M', 1});
+    put<int32_t>(head, (int32_t)hdr.text.size());
+    head.insert(head.end(), hdr.text.begin(), hdr.text.end());
+    put<int32_t>(head, (int32_t)hdr.ref_name.size());
+    for (size_t i = 0; i < hdr.ref_name.size(); ++i) {
+        put<int32_t>(head, (int32_t)hdr.ref_name[i].size() + 1);
+        head.insert(head.end(), hdr.ref_name[i].begin(), hdr.ref_name[i].end());
+        head.push_back(0);
+        put<int32_t>(head, (int32_t)hdr.ref_len[i]);
+    }
+    std::vector<uint8_t> file;
+    for (size_t off = 0; off < head.size(); off += kBlockIn)
+        if (!bgzf_block(head.data() + off, std::min(kBlockIn, head.size() - off), level, &file)) { *err = "deflate failed"; return false; }
+    const uint64_t header_end = file.size();
+
+    // ---- records: contiguous slices compressed independently (sortmardup/main.cpp:371-421)
+    const size_t n = recs.size();
+    const int T = std::max(1, threads);
+    const size_t n_slices = n ? std::min<size_t>((size_t)T * 4, (n + 4095) / 4096) : 0;
+    std::vector<Slice> slices(n_slices);
+    std::vector<size_t> lo(n_slices + 1, 0);
+    for (size_t s = 0; s <= n_slices; ++s) lo[s] = n_slices ? n * s / n_slices : 0;
+    {
+        std::vector<std::thread> pool;
+        size_t next = 0;
+        std::mutex* mu = new std::mutex;
+        for (int t = 0; t < T; ++t)
+            pool.emplace_back([&, mu]() {
+                for (;;) {
+                    size_t s;
+                    { std::lock_guard<std::mutex> g(*mu); if (next >= n_slices) return; s = next++; }
+                    compress_slice(recs, lo[s], lo[s + 1], level, &slices[s]);
+                }
+            });
+        for (auto& th : pool) th.join();
+        delete mu;
+    }
+    std::vector<uint64_t> base(n_slices + 1, header_end);
+    for (size_t s = 0; s < n_slices; ++s) {
+        if (!slices[s].ok) { *err = "deflate failed"; return false; }
+        base[s + 1] = base[s] + slices[s].bytes.size();
+    }
+
+    // ---- BAI (merge of the per-slice offsets, the job of the reference's merge_index)
+    std::vector<RefIndex> idx(hdr.ref_name.size());
+    uint64_t n_no_coor = 0;
+    for (size_t s = 0; s < n_slices; ++s)
+        for (size_t k = lo[s]; k < lo[s + 1]; ++k) {
+            const RecordRef& r = recs[k];
+            const uint64_t vb = rebase(slices[s].vbeg[k - lo[s]], base[s]), ve = rebase(slices[s].vend[k - lo[s]], base[s]);
+            if (r.tid < 0 || (size_t)r.tid >= idx.size()) { ++n_no_coor; continue; }
+            RefIndex& ri = idx[r.tid];
+            const int64_t beg = std::max<int64_t>(r.beg, 0), end = std::max<int64_t>(r.end, beg + 1);
+            auto& chunks = ri.bins[(uint32_t)reg2bin(beg, end)];
+            if (!chunks.empty() && chunks.back().second == vb) chunks.back().second = ve;   // contiguous: extend
+            else chunks.emplace_back(vb, ve);
+            const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+            if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+            for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == 0 || vb < ri.linear[w]) ri.linear[w] = vb;
+            ri.off_beg = std::min(ri.off_beg, vb); ri.off_end = std::max(ri.off_end, ve);
+            if (r.mapped) ++ri.n_mapped; else ++ri.n_unmapped;
+        }
+    std::vector<uint8_t> bai;
+    bai.insert(bai.end(), {'B', 'A', 'I', 1});
+    put<int32_t>(bai, (int32_t)idx.size());
+    for (RefIndex& ri : idx) {
+        const bool any = !ri.bins.empty();
+        put<int32_t>(bai, (int32_t)(ri.bins.size() + (any ? 1 : 0)));
+        for (auto& kv : ri.bins) {
+            put<uint32_t>(bai, kv.first);
+            put<int32_t>(bai, (int32_t)kv.second.size());
+            for (auto& c : kv.second) { put<uint64_t>(bai, c.first); put<uint64_t>(bai, c.second); }
+        }
+        if (any) {                                  // metadata pseudo-bin
+            put<uint32_t>(bai, 37450u); put<int32_t>(bai, 2);
+            put<uint64_t>(bai, ri.off_beg); put<uint64_t>(bai, ri.off_end);
+            put<uint64_t>(bai, ri.n_mapped); put<uint64_t>(bai, ri.n_unmapped);
+        }
+        // empty windows inherit the previous non-empty offset, as htslib's index does
+        uint64_t last = 0;
+        for (auto& v : ri.linear) { if (v == 0) v = last; else last = v; }
+        put<int32_t>(bai, (int32_t)ri.linear.size());
+        for (uint64_t v : ri.linear) put<uint64_t>(bai, v);
+    }
+    put<uint64_t>(bai, n_no_coor);
+
+    // ---- write both files
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { *err = "cannot open " + path; return false; }
+    bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+    for (size_t s = 0; ok && s < n_slices; ++s) ok = fwrite(slices[s].bytes.data(), 1, slices[s].bytes.size(), f) == slices[s].bytes.size();
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_block, 1, 28, f) == 28;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { *err = "short write to " + path; return false; }
+    f = fopen((path + ".bai").c_str(), "wb");
+    if (!f) { *err = "cannot open " + path + ".bai"; return false; }
+    ok = fwrite(bai.data(), 1, bai.size(), f) == bai.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { *err = "short write to " + path + ".bai"; return false; }
+    return true;
+}
+
+}  // namespace bamout

@@ -1,0 +1,35 @@
+// bam_writer.h -- BGZF / BAM / BAI output for the sortmardup-compatible CLI (fresh code on zlib).
+//
+// Replaces what sortmardup/main.cpp:359-465 does with a patched htslib (bam_write_idx2,
+// bgzf_flush2, hts_close2, merge_index, hts_idx_finish3 -- functions that exist nowhere in the
+// reference tree): per-thread compression of contiguous slices of the sorted records into
+// independent BGZF blocks, concatenation, and a BAI index built from the records' virtual offsets.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sam_text.h"
+
+namespace bamout {
+
+// BAM-encodes one record WITHOUT the leading block_size field (so the flag sits at byte 14).
+void encode_record(const samtext::Record& r, std::vector<uint8_t>* out);
+constexpr size_t kFlagOffset = 14;
+
+int reg2bin(int64_t beg, int64_t end);
+
+struct RecordRef {              // one record of the output, in output order
+    const uint8_t* blob;        // encode_record() bytes
+    uint32_t len;
+    int32_t tid, beg, end;      // for the index (end exclusive)
+    bool set_dup;               // OR 0x400 into the flag while writing
+    bool mapped;                // !(flag & 4), for the index metadata
+};
+
+// Writes <path> and <path>.bai.  Returns false and sets *err on I/O failure.
+bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
+               int threads, int level, std::string* err);
+
+}  // namespace bamout

@@ -1,0 +1,202 @@
+// sam_text.cpp -- see sam_text.h.  Follows the SAM/BAM specification (SAMv1 sections 1.4, 4.2).
+#include "sam_text.h"
+
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace samtext {
+
+int Header::find(const char* name, size_t len) const {
+    for (size_t i = 0; i < ref_name.size(); ++i)
+        if (ref_name[i].size() == len && memcmp(ref_name[i].data(), name, len) == 0) return (int)i;
+    return -1;
+}
+
+int32_t Record::end() const {
+    int64_t ref = 0;
+    for (uint32_t c : cigar) {
+        const uint32_t op = c & 15;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref += c >> 4;   // M D N = X
+    }
+    return (int32_t)(pos + (ref > 0 ? ref : 1));
+}
+
+size_t parse_header(const char* data, size_t size, Header* h) {
+    size_t off = 0;
+    while (off < size && data[off] == '@') {
+        const char* nl = (const char*)memchr(data + off, '\n', size - off);
+        const size_t len = nl ? (size_t)(nl - (data + off)) : size - off;
+        const char* line = data + off;
+        if (len >= 3 && line[1] == 'S' && line[2] == 'Q') {
+            std::string name; uint64_t ln = 0;
+            size_t i = 3;
+            while (i < len) {
+                if (line[i] == '\t') { ++i; continue; }
+                size_t j = i;
+                while (j < len && line[j] != '\t') ++j;
+                if (j - i >= 3 && line[i + 2] == ':') {
+                    if (line[i] == 'S' && line[i + 1] == 'N') name.assign(line + i + 3, j - i - 3);
+                    else if (line[i] == 'L' && line[i + 1] == 'N') ln = strtoull(std::string(line + i + 3, j - i - 3).c_str(), nullptr, 10);
+                }
+                i = j;
+            }
+            h->ref_name.push_back(name);
+            h->ref_len.push_back(ln);
+        }
+        h->text.append(line, len);
+        h->text.push_back('\n');
+        off += len + (nl ? 1 : 0);
+    }
+    return off;
+}
+
+namespace {
+
+const uint8_t* nt16_table() {
+    static uint8_t t[256];
+    static bool init = false;
+    if (!init) {
+        memset(t, 15, sizeof t);
+        const char* codes = "=ACMGRSVTWYHKDBN";
+        for (int i = 0; i < 16; ++i) { t[(uint8_t)codes[i]] = (uint8_t)i; t[(uint8_t)(codes[i] | 0x20)] = (uint8_t)i; }
+        init = true;
+    }
+    return t;
+}
+
+inline bool next_field(const char*& p, const char* end, const char** f, size_t* n) {
+    if (p > end) return false;
+    const char* t = (const char*)memchr(p, '\t', (size_t)(end - p));
+    *f = p;
+    *n = t ? (size_t)(t - p) : (size_t)(end - p);
+    p = t ? t + 1 : end + 1;
+    return true;
+}
+
+inline bool to_int(const char* f, size_t n, int64_t* v) {
+    if (n == 0 || n > 20) return false;
+    char buf[24];
+    memcpy(buf, f, n); buf[n] = 0;
+    char* e; errno = 0;
+    const long long x = strtoll(buf, &e, 10);
+    if (errno || *e) return false;
+    *v = x;
+    return true;
+}
+
+template <typename T>
+inline void put(std::vector<uint8_t>& a, T v) { const uint8_t* p = (const uint8_t*)&v; a.insert(a.end(), p, p + sizeof(T)); }
+
+// smallest BAM integer type holding v (what htslib chooses when it parses an 'i' tag)
+void put_int_tag(std::vector<uint8_t>& a, int64_t v) {
+    if (v < 0) {
+        if (v >= -128) { a.push_back('c'); put<int8_t>(a, (int8_t)v); }
+        else if (v >= -32768) { a.push_back('s'); put<int16_t>(a, (int16_t)v); }
+        else { a.push_back('i'); put<int32_t>(a, (int32_t)v); }
+    } else {
+        if (v <= 255) { a.push_back('C'); put<uint8_t>(a, (uint8_t)v); }
+        else if (v <= 65535) { a.push_back('S'); put<uint16_t>(a, (uint16_t)v); }
+        else { a.push_back('I'); put<uint32_t>(a, (uint32_t)v); }
+    }
+}
+
+bool parse_aux(const char* f, size_t n, std::vector<uint8_t>& a, std::string* err) {
+    if (n < 5 || f[2] != ':' || f[4] != ':') { *err = "malformed optional field"; return false; }
+    a.push_back((uint8_t)f[0]); a.push_back((uint8_t)f[1]);
+    const char type = f[3];
+    const char* v = f + 5; const size_t vn = n - 5;
+    std::string s(v, vn);
+    switch (type) {
+        case 'A': a.push_back('A'); a.push_back(vn ? (uint8_t)v[0] : 0); return true;
+        case 'i': { int64_t x; if (!to_int(v, vn, &x)) { *err = "bad integer tag"; return false; } put_int_tag(a, x); return true; }
+        case 'f': a.push_back('f'); put<float>(a, strtof(s.c_str(), nullptr)); return true;
+        case 'Z': case 'H': a.push_back((uint8_t)type); a.insert(a.end(), v, v + vn); a.push_back(0); return true;
+        case 'B': {
+            if (vn < 1) { *err = "bad B tag"; return false; }
+            const char sub = v[0];
+            std::vector<std::string> items;
+            size_t i = 1;
+            while (i < vn) { if (v[i] == ',') { ++i; continue; } size_t j = i; while (j < vn && v[j] != ',') ++j; items.emplace_back(v + i, j - i); i = j; }
+            a.push_back('B'); a.push_back((uint8_t)sub); put<uint32_t>(a, (uint32_t)items.size());
+            for (auto& it : items) {
+                switch (sub) {
+                    case 'c': put<int8_t>(a, (int8_t)strtol(it.c_str(), nullptr, 10)); break;
+                    case 'C': put<uint8_t>(a, (uint8_t)strtoul(it.c_str(), nullptr, 10)); break;
+                    case 's': put<int16_t>(a, (int16_t)strtol(it.c_str(), nullptr, 10)); break;
+                    case 'S': put<uint16_t>(a, (uint16_t)strtoul(it.c_str(), nullptr, 10)); break;
+                    case 'i': put<int32_t>(a, (int32_t)strtol(it.c_str(), nullptr, 10)); break;
+                    case 'I': put<uint32_t>(a, (uint32_t)strtoul(it.c_str(), nullptr, 10)); break;
+                    case 'f': put<float>(a, strtof(it.c_str(), nullptr)); break;
+                    default: *err = "bad B subtype"; return false;
+                }
+            }
+            return true;
+        }
+        default: *err = "unknown optional field type"; return false;
+    }
+}
+
+}  // namespace
+
+bool parse_record(const char* line, size_t len, const Header& h, Record* r, std::string* err) {
+    const char* p = line; const char* end = line + len;
+    const char* f[11]; size_t n[11];
+    for (int k = 0; k < 11; ++k)
+        if (!next_field(p, end, &f[k], &n[k])) { *err = "fewer than 11 fields"; return false; }
+    int64_t v;
+    r->qname.assign(f[0], n[0]);
+    if (n[0] == 0 || n[0] > 254) { *err = "bad QNAME length"; return false; }
+    if (!to_int(f[1], n[1], &v) || v < 0 || v > 65535) { *err = "bad FLAG"; return false; }
+    r->flag = (uint16_t)v;
+    r->tid = (n[2] == 1 && f[2][0] == '*') ? -1 : h.find(f[2], n[2]);
+    if (r->tid < 0 && !(n[2] == 1 && f[2][0] == '*')) { *err = "RNAME not in the header"; return false; }
+    if (!to_int(f[3], n[3], &v)) { *err = "bad POS"; return false; }
+    r->pos = (int32_t)v - 1;
+    if (!to_int(f[4], n[4], &v) || v < 0 || v > 255) { *err = "bad MAPQ"; return false; }
+    r->mapq = (uint8_t)v;
+    r->cigar.clear();
+    if (!(n[5] == 1 && f[5][0] == '*')) {
+        uint64_t num = 0; bool have = false;
+        for (size_t i = 0; i < n[5]; ++i) {
+            const char ch = f[5][i];
+            if (ch >= '0' && ch <= '9') { num = num * 10 + (uint64_t)(ch - '0'); have = true; continue; }
+            const char* ops = "MIDNSHP=XB";
+            const char* q = strchr(ops, ch);
+            if (!q || !have || num >= (1ull << 28)) { *err = "bad CIGAR"; return false; }
+            r->cigar.push_back((uint32_t)(num << 4) | (uint32_t)(q - ops));
+            num = 0; have = false;
+        }
+        if (have) { *err = "bad CIGAR"; return false; }
+    }
+    if (n[6] == 1 && f[6][0] == '=') r->mtid = r->tid;
+    else if (n[6] == 1 && f[6][0] == '*') r->mtid = -1;
+    else { r->mtid = h.find(f[6], n[6]); if (r->mtid < 0) { *err = "RNEXT not in the header"; return false; } }
+    if (!to_int(f[7], n[7], &v)) { *err = "bad PNEXT"; return false; }
+    r->mpos = (int32_t)v - 1;
+    if (!to_int(f[8], n[8], &v)) { *err = "bad TLEN"; return false; }
+    r->tlen = (int32_t)v;
+    const uint8_t* nt16 = nt16_table();
+    if (n[9] == 1 && f[9][0] == '*') { r->l_seq = 0; r->seq4.clear(); }
+    else {
+        r->l_seq = (uint32_t)n[9];
+        r->seq4.assign((n[9] + 1) / 2, 0);
+        for (size_t i = 0; i < n[9]; ++i) r->seq4[i >> 1] |= (uint8_t)(nt16[(uint8_t)f[9][i]] << ((~i & 1) << 2));
+    }
+    if (n[10] == 1 && f[10][0] == '*') r->qual.assign(r->l_seq, 0xFF);
+    else {
+        if (n[10] != r->l_seq) { *err = "SEQ and QUAL differ in length"; return false; }
+        r->qual.resize(r->l_seq);
+        for (size_t i = 0; i < n[10]; ++i) r->qual[i] = (uint8_t)(f[10][i] - 33);
+    }
+    r->aux.clear();
+    const char* af; size_t an;
+    while (p <= end && next_field(p, end, &af, &an)) {
+        if (an == 0) continue;
+        if (!parse_aux(af, an, r->aux, err)) return false;
+    }
+    return true;
+}
+
+}  // namespace samtext
