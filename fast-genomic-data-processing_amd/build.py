@@ -12,6 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgx.so")
 SOURCES = ["mgx_common.cpp", "mgx_tables.cpp", "sortdedup_pack.cpp", "mgx_pairhmm.hip", "mgx_sortdedup.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-ffp-contract=off",
+         # the reference runs with MXCSR.FTZ set (IntelPairHmm.cc:230), which flushes fp64 results too
+         "-Xarch_device", "-fdenormal-fp-math=preserve-sign",
          "-Wall", "-Wno-unused-function"]
 
 
@@ -21,7 +23,7 @@ def _newest(paths):
 
 def build(force=False, verbose=True):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+    deps = [os.path.abspath(__file__)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))] + [
         os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
         return LIB

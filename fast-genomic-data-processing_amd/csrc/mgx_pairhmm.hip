@@ -26,17 +26,22 @@ using mgx::set_error;
 
 namespace {
 
-constexpr int kMaxRowsG16 = 16 * 8;
-constexpr int kMaxRowsG64 = 64 * 8;
+// Row classes: G = 16 lanes per pair with 1..12 rows per lane (reads up to 192 bases: the common
+// 100-151 bp short reads stay on the 4-pairs-per-wavefront shape), G = 64 with 4..16 rows per lane
+// beyond that (up to 1024 bases).
+constexpr int kG16MaxRPL = 12, kG64MinRPL = 4, kG64MaxRPL = 16;
+constexpr int kMaxRowsG16 = 16 * kG16MaxRPL;
+constexpr int kMaxRowsG64 = 64 * kG64MaxRPL;
 constexpr uint32_t kMaxLdsPerBlock = 64 * 1024;
 
 struct Bin {
-    int G = 0, RPL = 0;
+    int G = 0, RPL = 0;              // fp32 kernel shape
+    int Gd = 0, RPLd = 0;            // fp64 re-run kernel shape (fewer registers per row class)
     uint32_t job_begin = 0, job_count = 0;
     uint32_t max_h = 0;
     uint64_t cells = 0, alg_bytes = 0;
     // launch geometry
-    uint32_t block = 256, lds_stride = 0, grid_f32 = 0, grid_f64 = 0;
+    uint32_t block = 256, lds_stride = 0, grid_f32 = 0, grid_f64 = 0, grid_f64_all = 0;
 };
 
 }  // namespace
@@ -110,40 +115,48 @@ int upload(T** dst, const void* src, size_t bytes, hipStream_t s) {
 // (G, RPL) class of a read of R rows; G = 0 if unsupported.
 inline void shape_of(uint32_t R, int* G, int* RPL) {
     if (R <= (uint32_t)kMaxRowsG16) { *G = 16; *RPL = (int)((R + 15) / 16); }
-    else if (R <= (uint32_t)kMaxRowsG64) { *G = 64; *RPL = (int)((R + 63) / 64); }
+    else if (R <= (uint32_t)kMaxRowsG64) { *G = 64; *RPL = std::max(kG64MinRPL, (int)((R + 63) / 64)); }
     else { *G = 0; *RPL = 0; }
 }
 // dynamic LDS of one block: per-wavefront emission table (fp32 only) + per-group haplotype codes
 inline uint32_t lds_bytes(const Bin& bin, bool f32) {
-    const uint32_t waves = bin.block / 64u, groups = bin.block / (uint32_t)bin.G;
+    const uint32_t waves = bin.block / 64u, groups = bin.block / (uint32_t)(f32 ? bin.G : bin.Gd);
     const uint32_t etab = f32 ? (uint32_t)((bin.RPL + 1) / 2) * kNumCodes * 512u : 0u;
     return waves * etab + groups * bin.lds_stride;
 }
-inline int bin_index(int G, int RPL) { return (G == 16 ? 0 : 8) + RPL - 1; }
-constexpr int kBins = 16;
+constexpr int kBins = kG16MaxRPL + (kG64MaxRPL - kG64MinRPL + 1);
+inline int bin_index(int G, int RPL) { return G == 16 ? RPL - 1 : kG16MaxRPL + RPL - kG64MinRPL; }
+inline void bin_shape(int k, Bin* b) {
+    if (k < kG16MaxRPL) { b->G = 16; b->RPL = k + 1; } else { b->G = 64; b->RPL = k - kG16MaxRPL + kG64MinRPL; }
+    // the fp64 kernel keeps twice the registers per row: beyond 8 rows per lane of 16 it runs one
+    // pair per wavefront instead
+    if (b->G == 16 && b->RPL > 8) { b->Gd = 64; b->RPLd = (16 * b->RPL + 63) / 64; } else { b->Gd = b->G; b->RPLd = b->RPL; }
+}
 constexpr uint64_t kMergeBelow = 4096;
 
 // launch geometry of a bin once job_count and max_h are known
 int finalize_bin(Bin& bin, int n_cu) {
     // LDS per group: G pad + codes + G pad + prefetch slack (see the kernel's staging loop)
-    bin.lds_stride = (bin.max_h + 2u * (uint32_t)bin.G + 8u + 15u) & ~15u;
+    bin.lds_stride = (bin.max_h + 2u * (uint32_t)std::max(bin.G, bin.Gd) + 8u + 15u) & ~15u;
     bin.block = 128;                  // 2 wavefronts: fine-grained LDS/VGPR packing per CU
     while (bin.block > 64u && lds_bytes(bin, true) > kMaxLdsPerBlock) bin.block /= 2;
     if (lds_bytes(bin, true) > 160u * 1024u) {
         set_error("haplotype of %u bases does not fit the LDS staging buffer", bin.max_h);
         return -E2BIG;
     }
-    const uint32_t gpb = bin.block / bin.G;
+    const uint32_t gpb = bin.block / bin.G, gpbd = bin.block / bin.Gd;
     bin.grid_f32 = (bin.job_count + gpb - 1) / gpb;
-    bin.grid_f64 = std::min<uint32_t>(bin.grid_f32, (uint32_t)n_cu * 8u);
+    bin.grid_f64_all = (bin.job_count + gpbd - 1) / gpbd;
+    bin.grid_f64 = std::min<uint32_t>(bin.grid_f64_all, (uint32_t)n_cu * 8u);
     return 0;
 }
 // fold sparsely populated bins into the next larger row class of the same group width
 void merge_small_bins(uint64_t (&count)[kBins], int (&remap)[kBins]) {
     for (int k = 0; k < kBins; ++k) remap[k] = k;
-    for (int base = 0; base < kBins; base += 8)
-        for (int k = base; k < base + 7; ++k)
-            if (count[k] && count[k] < kMergeBelow) { count[k + 1] += count[k]; count[k] = 0; remap[k] = k + 1; }
+    for (int k = 0; k + 1 < kBins; ++k) {
+        if (k + 1 == kG16MaxRPL) continue;                      // never across the group-width boundary
+        if (count[k] && count[k] < kMergeBelow) { count[k + 1] += count[k]; count[k] = 0; remap[k] = k + 1; }
+    }
     for (int k = 0; k < kBins; ++k) { int t = k; while (remap[t] != t) t = remap[t]; remap[k] = t; }
 }
 
@@ -347,8 +360,7 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
     for (int k = 0; k < kBins; ++k) {
         if (!reads_in[k]) continue;
         Bin bin;
-        bin.G = k < 8 ? 16 : 64;
-        bin.RPL = (k % 8) + 1;
+        bin_shape(k, &bin);
         bin.job_begin = (uint32_t)job_begin;
         bin.job_count = (uint32_t)(reads_in[k] * nh);
         bin.max_h = max_h;
@@ -477,8 +489,7 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
         for (int k = 0; k < kBins; ++k) {
             if (!count[k]) continue;
             Bin bin;
-            bin.G = k < 8 ? 16 : 64;
-            bin.RPL = (k % 8) + 1;
+            bin_shape(k, &bin);
             bin.job_begin = (uint32_t)bin_start[k];
             bin.job_count = (uint32_t)count[k];
             for (uint64_t q = bin_start[k]; q < bin_start[k + 1]; ++q) {
@@ -555,10 +566,10 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d;
             if (force_f64) { a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count; }
             else { a.job_list = b->d_rerun_list + bin.job_begin; a.n_dyn = b->d_rerun_count + k; a.n_static = 0; }
-            KernelFn f = pick_kernel<double>(bin.G, bin.RPL);
-            if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
+            KernelFn f = pick_kernel<double>(bin.Gd, bin.RPLd);
+            if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", bin.Gd, bin.RPLd); return -ENOSYS; }
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 2], s));
-            hipLaunchKernelGGL(f, dim3(force_f64 ? bin.grid_f32 : bin.grid_f64), dim3(bin.block), lds_bytes(bin, false), s, a);
+            hipLaunchKernelGGL(f, dim3(force_f64 ? bin.grid_f64_all : bin.grid_f64), dim3(bin.block), lds_bytes(bin, false), s, a);
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 3], s));
         }
     }

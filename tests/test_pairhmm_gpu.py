@@ -34,7 +34,8 @@ def test_one_shot_compute_matches_staged(engine):
 
 
 @pytest.mark.parametrize("r_range,h_range,n", [((1, 128), (1, 256), 20000), ((100, 128), (200, 256), 8000),
-                                                ((129, 512), (10, 600), 1500), ((1, 16), (1, 40), 5000)])
+                                                ((129, 512), (10, 600), 1500), ((1, 16), (1, 40), 5000),
+                                                ((129, 192), (100, 400), 6000), ((513, 1024), (300, 1200), 300)])
 def test_random_ragged_vs_oracle(engine, oracle, synth, r_range, h_range, n):
     d = synth.gen_pairhmm_pairs(n, 0x5EED0002 ^ n, r_range=r_range, h_range=h_range, hap_n_rate=0.01)
     want, wused = oracle.batch(d)
@@ -98,7 +99,7 @@ def test_full_size_properties(engine, oracle, synth):
 
 
 def test_read_longer_than_supported_is_an_error_not_a_fallback(pkg, engine, synth):
-    d = synth.gen_pairhmm_pairs(4, 3, r_range=(513, 513), h_range=(600, 600))
+    d = synth.gen_pairhmm_pairs(4, 3, r_range=(1025, 1025), h_range=(1100, 1100))
     with pytest.raises(pkg.MgxError, match="row limit"):
         engine.compute(d)
 
