@@ -120,8 +120,10 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch):
                "device_ms": st["ms_total"], "upload_s": upload_s,
                "pcie_inclusive_mrecords_s": n / (upload_s + st["ms_total"] * 1e-3) / 1e6,
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                            "kernel": "k_radix_scatter (all launches of one run)", "kernel_ms": ms_scatter_avg,
+                            "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": measured_traffic("k_radix_scatter<true, false>"),
+                            "kernel": "k_radix_scatter (all launches of one run; traffic: the <true, false> "
+                                      "double-pair form, 9 of the 18 launches)", "kernel_ms": ms_scatter_avg,
                             "alg_bytes_per_launch": bytes_per_scatter,
                             "note": "algorithmic bytes = keys+payload read once and written once per pass"},
                "model_roofline": {"alg_bytes": st["alg_bytes"], "achieved": st["alg_bytes"] / (st["ms_total"] * 1e-3) / 1e9,
