@@ -201,6 +201,11 @@ int validate(const mgx_pairhmm_input_t* in) {
         return -EINVAL;
     }
     if (in->n_pairs > 0xFFFFFFF0ull) { set_error("more than 2^32 test cases in one batch"); return -E2BIG; }
+    // offsets index device memory: a decreasing table would turn into an out-of-bounds access there
+    for (uint64_t r = 0; r < in->n_reads; ++r)
+        if (in->read_off[r + 1] < in->read_off[r]) { set_error("read_off is not monotonic at %llu", (unsigned long long)r); return -EINVAL; }
+    for (uint64_t h = 0; h < in->n_haps; ++h)
+        if (in->hap_off[h + 1] < in->hap_off[h]) { set_error("hap_off is not monotonic at %llu", (unsigned long long)h); return -EINVAL; }
     return 0;
 }
 

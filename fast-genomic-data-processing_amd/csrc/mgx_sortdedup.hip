@@ -54,7 +54,7 @@ constexpr int kWalkCap = 64;                          // longest run a single la
 struct Scalars {            // device-side scalars, one 64-byte read-back
     u64 max_coord, max_k1d, max_k2d, max_k1s;
     u32 n_double, n_single, n_long_d, n_long_s;
-    u32 n_dup, pad_[3];
+    u32 n_dup, bad_mate, pad_[2];   // bad_mate: a record names a mate index outside the shard
 };
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
             if (i < n) {
                 // classify() needs flag and mate only: bytes 16..21 of the 32-byte record
                 const u32 mate = recs[i].mate; const u32 flag = recs[i].flag;
-                const int c = (flag & kIgnorable) ? 0 : (mate == MGX_NO_MATE ? 2 : (mate > i ? 1 : 0));
+                const int c = ((flag & kIgnorable) || (mate != MGX_NO_MATE && mate >= n)) ? 0 : (mate == MGX_NO_MATE ? 2 : (mate > i ? 1 : 0));
                 cd += c == 1; cs += c == 2;
             }
         }
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
         mgx_rec_t r;
         if (i < n) {
             r = recs[i];
+            if (r.mate != MGX_NO_MATE && r.mate >= n) { sc->bad_mate = 1; r.mate = MGX_NO_MATE; r.flag |= (uint16_t)kIgnorable; }
             c = classify(r, i);
             o.ckey[i] = o.packed_coord ? ((u64)r.coord << 32) | i : (u64)r.coord;
             if (!o.packed_coord) o.cval[i] = i;
@@ -758,6 +759,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         }
         break;
     }
+    if (c->sc.bad_mate) { set_error("a record's mate index is outside the uploaded shard"); return -EINVAL; }
     const u32 nd = c->sc.n_double, ns = c->sc.n_single;
     c->stats.n_double = nd; c->stats.n_single = ns;
     c->stats.key_bits_coord = bits_of(c->sc.max_coord);

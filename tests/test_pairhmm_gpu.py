@@ -138,3 +138,12 @@ def test_result_does_not_depend_on_batch_composition(engine, synth):
         sub = dict(d)
         sub["pair_read"], sub["pair_hap"] = d["pair_read"][idx], d["pair_hap"][idx]
         assert np.array_equal(engine.compute(sub), full[idx])
+
+
+def test_non_monotonic_offsets_are_rejected(pkg, engine, synth):
+    d = synth.gen_pairhmm_pairs(16, 3, r_range=(10, 20), h_range=(20, 30))
+    d = dict(d)
+    ro = d["read_off"].copy(); ro[5], ro[6] = ro[6], ro[5]
+    d["read_off"] = ro
+    with pytest.raises(pkg.MgxError, match="monotonic"):
+        engine.compute(d)

@@ -121,3 +121,11 @@ def test_wrapped_five_prime_forces_the_fallback(sd_engine, sd_oracle, synth):
     want_order, want_dup, _ = sd_oracle.run(L, recs)
     order, dup = sd_engine.sort_mark(L, recs)
     assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
+
+
+def test_out_of_range_mate_is_an_error_not_a_fault(pkg, sd_engine, synth):
+    recs, L = synth.gen_sortdedup_packed(10_000, 3, n_contigs=2, contig_len=1_000_000)
+    recs = recs.copy()
+    recs["mate"][77] = 5_000_000
+    with pytest.raises(pkg.MgxError, match="mate index"):
+        sd_engine.sort_mark(L, recs)
