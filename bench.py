@@ -77,7 +77,7 @@ def cpu_baseline(synth, n_sample, seed):
                       f"{d['cells'] / 1e9:.2f} Gcells in {dt:.2f} s wall on {cores} threads"}
 
 
-def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch):
+def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend="nccl"):
     """GPU radix sort + duplicate marking over a resident shard of packed records; every rank owns a
     coordinate-independent shard of its own (weak scaling, no collective on the data path)."""
     recs, L = synth.gen_sortdedup_packed(args.sort_records, 0x5EED0004 + 0x1000 * rank)
@@ -101,7 +101,7 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch):
     dt = time.perf_counter() - t0
     tmax = dt
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
     out = None
@@ -121,7 +121,7 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch):
                "pcie_inclusive_mrecords_s": n / (upload_s + st["ms_total"] * 1e-3) / 1e6,
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": measured_traffic("k_radix_scatter<true, false>"),
+                            "traffic": measured_traffic("k_radix_scatter<true, false>") if n == 200_000_000 else None,
                             "kernel": "k_radix_scatter (all launches of one run; traffic: the <true, false> "
                                       "double-pair form, 9 of the 18 launches)", "kernel_ms": ms_scatter_avg,
                             "alg_bytes_per_launch": bytes_per_scatter,
@@ -161,12 +161,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    backend = os.environ.get("MGX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on one GPU
+    n_dev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(n_dev, 1)          # ranks share the card in a rehearsal
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
@@ -205,7 +212,7 @@ def main():
 
     tmax = dt
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
     cells_per_step_all = d["cells"] * world             # every rank holds an equal-size shard
@@ -224,7 +231,8 @@ def main():
                        "pairs_per_gpu": args.pairs, "read_len": 128, "hap_len": 256, "seed": hex(seed),
                        "rerun_f64_per_step": st["n_rerun_f64"], "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(st["dominant_kernel"]),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(st["dominant_kernel"]) if args.pairs == (1 << 20) else None,
                          "kernel": st["dominant_kernel"], "kernel_ms": ms_dom,
                          "alg_bytes_per_launch": alg_bytes,
                          "note": "5R+H+4 algorithmic bytes per test case (SURVEY.md 8d); the kernel is "
@@ -244,7 +252,7 @@ def main():
     # ---- second half of BASELINE.json's metric: sortmardup Mrecords/s (configs[3]) ------------
     sort_line = None
     if args.sort_records > 0:
-        sort_line = sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch)
+        sort_line = sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend)
     if rank == 0:
         if sort_line is not None:
             line["sortmardup"] = sort_line
