@@ -147,3 +147,60 @@ def test_non_monotonic_offsets_are_rejected(pkg, engine, synth):
     d["read_off"] = ro
     with pytest.raises(pkg.MgxError, match="monotonic"):
         engine.compute(d)
+
+
+def test_long_haplotypes(pkg, engine, oracle, synth):
+    """Haplotypes far beyond the usual few hundred bases: the per-group LDS staging buffer grows and
+    the workgroup shrinks; beyond what LDS can hold the call fails loudly."""
+    d = synth.gen_pairhmm_pairs(48, 11, r_range=(60, 150), h_range=(9000, 20000))
+    want, _ = oracle.batch(d)
+    out = engine.compute(d)
+    assert_log10_close(out, want)
+    d = synth.gen_pairhmm_pairs(4, 12, r_range=(100, 100), h_range=(70000, 70000))
+    with pytest.raises(pkg.MgxError, match="LDS staging"):
+        engine.compute(d)
+
+
+def test_one_context_per_worker_thread(pkg, synth):
+    """The reference runs one VectorLoglessPairHMM per worker thread (Mutect2Engine.cpp:27-29,
+    main.cpp:570-574).  Four host threads, each with its own context, stream regions concurrently;
+    every result must equal the single-threaded one bit for bit, and recycled slabs must not leak
+    one region's data into the next."""
+    import threading
+    regions = [synth.gen_pairhmm_region(20 + 3 * k, 5 + k % 7, 100 + k, r_range=(30, 140), h_range=(60, 300)) for k in range(24)]
+    for r in regions:
+        r["pair_read"] = None; r["pair_hap"] = None
+    ref_eng = pkg.PairHMMEngine(0)
+    want = [ref_eng.compute(r) for r in regions]
+    ref_eng.close()
+    got = [None] * len(regions)
+    errors = []
+
+    def worker(tid):
+        try:
+            eng = pkg.PairHMMEngine(0)
+            for rep in range(3):
+                for k in range(tid, len(regions), 4):
+                    got[k] = eng.compute(regions[k])
+                    assert np.array_equal(got[k], want[k]), (tid, rep, k)
+            eng.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
+def test_batches_in_flight(engine, oracle, synth):
+    """Several batches created and run before any result is fetched (the staged ABI)."""
+    ds = [synth.gen_pairhmm_pairs(3000 + 500 * k, 900 + k, r_range=(10, 128), h_range=(20, 256)) for k in range(5)]
+    bs = [engine.batch(d) for d in ds]
+    for b in bs: b.run()
+    for b in reversed(bs): b.run()          # a batch may be run again
+    for d, b in zip(ds, bs):
+        want, _ = oracle.batch(d)
+        assert_log10_close(b.results(), want)
+        b.close()
