@@ -664,7 +664,20 @@ int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+    {
+        // optional CU partition (flags bits 8..15: an 8-bit pattern repeated over the CU index): lets a
+        // VALU-bound PairHMM context and an HBM-bound sort context share one GPU side by side instead
+        // of queueing behind each other (BASELINE.json configs[4])
+        const unsigned pat = (flags >> 8) & 0xFFu;
+        if (pat != 0 && pat != 0xFFu) {
+            const int n_words = (c->n_cu + 31) / 32;
+            std::vector<uint32_t> mask(n_words, 0);
+            for (int cu = 0; cu < c->n_cu; ++cu) if ((pat >> (cu & 7)) & 1u) mask[cu >> 5] |= 1u << (cu & 31);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->compute, (uint32_t)n_words, mask.data()));
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+        }
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void**)&c->d_sc, sizeof(Scalars)));
     HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_stop));

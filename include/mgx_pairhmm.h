@@ -46,6 +46,9 @@ typedef struct mgx_pairhmm_batch mgx_pairhmm_batch_t;
 /* flags for mgx_pairhmm_create */
 #define MGX_PAIRHMM_FORCE_DOUBLE 1u /* PairHMMNativeArgumentCollection.useDoublePrecision */
 #define MGX_PAIRHMM_TIMING       2u /* record HIP events around every kernel launch */
+/* bits 8..15 (both mgx_pairhmm_create and mgx_sortdedup_create): optional CU partition, an 8-bit
+ * pattern repeated over the CU index; 0 or 0xFF = all CUs.  MGX_CU_PATTERN(0x3F) keeps 6 CUs of 8. */
+#define MGX_CU_PATTERN(p) (((unsigned)(p) & 0xFFu) << 8)
 
 /* Packed host-side description of one batch of test cases. */
 typedef struct mgx_pairhmm_input {

@@ -20,7 +20,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    return importlib.import_module(PKG)
+    """The package, with libmgx.so built on demand (it is git-ignored; hipcc cross-compiles
+    without a GPU), so a fresh checkout can run the suite without a separate build step."""
+    m = importlib.import_module(PKG)
+    if not os.path.exists(m.lib_path()):
+        importlib.import_module(PKG + ".build").build()
+    return m
 
 
 @pytest.fixture(scope="session")

@@ -197,7 +197,7 @@ def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads):
     assert indexed == sum(1 for r in recs if r["tid"] >= 0)
 
 
-def test_cli_usage_and_build():
+def test_cli_usage_and_build(pkg):
     exe = build_cli()
     res = subprocess.run([exe], capture_output=True, text=True)
     assert res.returncode == 2 and "usage" in res.stderr
