@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -84,6 +85,13 @@ struct mgx_pairhmm_batch {
     uint32_t* d_rerun_count = nullptr;
     double* d_out = nullptr;
     std::vector<Job> host_jobs;    // only kept for unstaged (very large) batches
+    // whole-region form (mgx_pairhmm_region): normalise / filter epilogue over [n_reads][n_haps]
+    bool has_model = false;
+    uint32_t n_reads = 0, n_haps = 0;
+    uint64_t* d_read_len = nullptr;
+    uint8_t* d_keep = nullptr;
+    size_t o_keep = 0;
+    double log10_rate = 0, max_err = 0;
     hipEvent_t uploaded = nullptr;
     // timing
     std::vector<hipEvent_t> ev;    // 4 per bin: f32 start/stop, f64 start/stop
@@ -301,7 +309,8 @@ namespace {
 
 // Batch of every read against every haplotype (pair_read == pair_hap == NULL):
 // out[r * n_haps + h].  Host work is O(n_reads + n_haps); job descriptors are made on the device.
-int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_batch* b) {
+int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_batch* b,
+                 const uint8_t* mapq = nullptr, const mgx_read_model_t* model = nullptr) {
     const uint64_t nr = in->n_reads, nh = in->n_haps;
     const uint64_t n = nr * nh;
     if (n > 0xFFFFFFF0ull) { set_error("more than 2^32 test cases in one batch"); return -E2BIG; }
@@ -346,10 +355,13 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
     const size_t o_del = off;   off = align_up(off + read_bytes);
     const size_t o_gcp = off;   off = align_up(off + read_bytes);
     const size_t o_hap = off;   off = align_up(off + hap_bytes);
+    const size_t o_mapq = off;  off = align_up(off + (model ? nr : 0));
+    const size_t o_rlen = off;  off = align_up(off + (model ? nr * sizeof(uint64_t) : 0));
     b->in_bytes = off;
     const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
     b->o_out = off;             off = align_up(off + n * sizeof(double));
     b->o_used = off;            off = align_up(off + n);
+    b->o_keep = off;            off = align_up(off + (model ? nr : 0));
     b->result_bytes = off - b->o_out;
     const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
@@ -373,7 +385,30 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
     memcpy(pin + o_ins, in->ins, read_bytes);     memcpy(pin + o_del, in->del, read_bytes);
     memcpy(pin + o_gcp, in->gcp, read_bytes);     memcpy(pin + o_hap, in->hap_bases, hap_bytes);
     hipStream_t s = c->copy;
+    if (model) {
+        for (uint64_t r = 0; r < nr; ++r) {
+            if (in->read_off[r + 1] - in->read_off[r] > 1024) { set_error("read longer than 1024 bases"); return -E2BIG; }
+            ((uint64_t*)(pin + o_rlen))[r] = in->read_off[r + 1] - in->read_off[r];
+        }
+        memcpy(pin + o_mapq, mapq, nr);
+        b->has_model = true; b->n_reads = (uint32_t)nr; b->n_haps = (uint32_t)nh;
+        b->d_read_len = (uint64_t*)(dv + o_rlen); b->d_keep = dv + b->o_keep;
+        b->log10_rate = model->log10_mismapping_rate; b->max_err = model->max_error_per_base;
+    }
     HIP_TRY(hipMemcpyAsync(dv, pin, b->in_bytes, hipMemcpyHostToDevice, s));
+    if (model) {
+        // modifyReadQualities + gap continuation penalties, in place on the uploaded arrays
+        ReadModel rm{};
+        rm.rate_factor = model->pcr_rate_factor; rm.bq_threshold = model->base_quality_threshold;
+        rm.constant_gcp = model->constant_gcp;
+        for (int i = 0; i <= 20; ++i) {      // PairHMMLikelihoodCalculationEngine.cpp:45-61
+            const double d = 40.0 - std::exp((double)i / ((double)std::max(rm.rate_factor, 1) * M_PI));
+            const int v = (d > 0.0 ? (int)(d + 0.5) : (int)(d - 0.5)) + 1;
+            rm.pcr_cache[i] = (uint8_t)(char)std::max(10, v);
+        }
+        hipLaunchKernelGGL(pairhmm_read_model, dim3((uint32_t)nr), dim3(128), 0, s, (const SeqRef*)(dv + o_rtab),
+                           b->d_bases, b->d_qual, b->d_ins, b->d_del, b->d_gcp, (const uint8_t*)(dv + o_mapq), rm);
+    }
     uint64_t job_begin = 0;
     for (int k = 0; k < kBins; ++k) {
         if (!reads_in[k]) continue;
@@ -591,6 +626,9 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 3], s));
         }
     }
+    if (b->has_model)
+        hipLaunchKernelGGL(pairhmm_normalize_filter, dim3((b->n_reads + 3) / 4), dim3(256), 0, s, b->d_out, b->d_read_len,
+                           b->n_reads, b->n_haps, b->log10_rate, b->max_err, b->d_keep);
     HIP_TRY(hipGetLastError());
     b->ran = true;
     return 0;
@@ -665,6 +703,45 @@ int mgx_pairhmm_batch_results(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, double* 
     if (used_f64) HIP_TRY(hipMemcpyAsync(used_f64, b->d_used, b->n_pairs, hipMemcpyDeviceToHost, c->compute));
     HIP_TRY(hipStreamSynchronize(c->compute));
     return 0;
+}
+
+void mgx_read_model_defaults(mgx_read_model_t* m) {
+    if (!m) return;
+    m->pcr_rate_factor = 3;             // CONSERVATIVE, LikelihoodEngineArgumentCollection.h:30
+    m->base_quality_threshold = 18;     // PairHMM::BASE_QUALITY_SCORE_THRESHOLD, PairHMM.h:18
+    m->constant_gcp = 10;               // gcpHMM
+    m->log10_mismapping_rate = -4.5;    // phredScaledGlobalReadMismappingRate = 45
+    m->max_error_per_base = 0.02;       // EXPECTED_ERROR_RATE_PER_BASE
+}
+
+int mgx_pairhmm_region(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const uint8_t* mapq,
+                       const mgx_read_model_t* model, double* out_log10, uint8_t* out_keep) {
+    if (!c || !in || !mapq || !model || !out_log10) { set_error("NULL argument"); return -EINVAL; }
+    if (in->pair_read || in->pair_hap) { set_error("mgx_pairhmm_region takes the cross-product form (pair arrays NULL)"); return -EINVAL; }
+    int rc = validate(in);
+    if (rc) return rc;
+    if (in->n_reads == 0 || in->n_haps == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
+        new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+    if (!b) return -ENOMEM;
+    if ((rc = create_cross(c, in, b.get(), mapq, model))) return rc;
+    mgx_pairhmm_batch* raw = b.release();
+    rc = mgx_pairhmm_batch_run(c, raw);
+    if (!rc) {
+        uint8_t* pin = raw->slab.pin;
+        rc = [&]() -> int {
+            HIP_TRY(hipMemcpyAsync(pin + raw->o_out, raw->d_out, raw->result_bytes, hipMemcpyDeviceToHost, c->compute));
+            HIP_TRY(hipStreamSynchronize(c->compute));
+            return 0;
+        }();
+        if (!rc) {
+            memcpy(out_log10, pin + raw->o_out, raw->n_pairs * sizeof(double));
+            if (out_keep) memcpy(out_keep, pin + raw->o_keep, raw->n_reads);
+        }
+    }
+    mgx_pairhmm_batch_destroy(c, raw);
+    return rc;
 }
 
 int mgx_pairhmm_compute(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, double* out_log10) {

@@ -33,6 +33,11 @@ class PairHMMStats(C.Structure):
     ]
 
 
+class ReadModel(C.Structure):
+    _fields_ = [("pcr_rate_factor", C.c_int), ("base_quality_threshold", C.c_int), ("constant_gcp", C.c_int),
+                ("log10_mismapping_rate", C.c_double), ("max_error_per_base", C.c_double)]
+
+
 # every symbol include/mgx_pairhmm.h declares: name -> (restype, argtypes)
 PAIRHMM_SYMBOLS = {
     "mgx_last_error": (C.c_char_p, []),
@@ -45,6 +50,8 @@ PAIRHMM_SYMBOLS = {
     "mgx_pairhmm_batch_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PairHMMStats)]),
     "mgx_pairhmm_batch_destroy": (None, [C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_sync": (C.c_int, [C.c_void_p]),
+    "mgx_read_model_defaults": (None, [C.c_void_p]),
+    "mgx_pairhmm_region": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_table_f32": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mgx_pairhmm_table_f64": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
 }

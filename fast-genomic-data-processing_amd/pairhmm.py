@@ -96,6 +96,22 @@ class PairHMMEngine:
         native.check(self.lib.mgx_pairhmm_compute(self.ctx, C.byref(inp), _ptr(out)))
         return out
 
+    def region(self, d, mapq, **model_overrides):
+        """computeReadLikelihoods for one sample on the device: raw qualities in, normalised
+        [n_reads][n_haps] log10 likelihoods and the keep mask of filterPoorlyModeledEvidence out."""
+        d = dict(d); d["pair_read"] = None; d["pair_hap"] = None
+        inp, keep = make_input(d)
+        m = native.ReadModel()
+        self.lib.mgx_read_model_defaults(C.byref(m))
+        for k, v in model_overrides.items():
+            setattr(m, k, v)
+        mq = np.ascontiguousarray(mapq, dtype=np.uint8)
+        n_reads, n_haps = len(keep["read_off"]) - 1, len(keep["hap_off"]) - 1
+        out = np.empty((n_reads, n_haps), dtype=np.float64)
+        kept = np.zeros(n_reads, dtype=np.uint8)
+        native.check(self.lib.mgx_pairhmm_region(self.ctx, C.byref(inp), _ptr(mq), C.byref(m), _ptr(out), _ptr(kept)))
+        return out, kept
+
     def batch(self, d):
         return PairHMMBatch(self, d)
 

@@ -111,6 +111,28 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* ctx, mgx_pairhmm_batch_t* batch,
 void mgx_pairhmm_batch_destroy(mgx_pairhmm_t* ctx, mgx_pairhmm_batch_t* batch);
 int mgx_pairhmm_sync(mgx_pairhmm_t* ctx);
 
+/* Whole-region form (row F2 of SURVEY.md 8f): what PairHMMLikelihoodCalculationEngine::
+ * computeReadLikelihoods does for one sample (haplotypecaller/PairHMMLikelihoodCalculationEngine.cpp:63-97)
+ * in one call -- on the device, between one upload and one download:
+ *   modifyReadQualities   PCR indel error model from tandem-repeat length, base quality capped by
+ *                         MAPQ, low qualities squashed to 6                      (:123-282)
+ *   gap continuation      constant penalty                                     (:284-292)
+ *   PairHMM               every read x every haplotype (`in` in cross-product form, raw qualities)
+ *   normalizeLikelihoods  cap every haplotype at best + log10 mismapping rate  (AlleleLikelihoods.h:372-391)
+ *   filterPoorlyModeledEvidence   out_keep[r] = 0 for reads it would drop      (AlleleLikelihoods.h:404-419)
+ * out_log10 is [n_reads][n_haps]; mapq is one byte per read.  Parity of this row is pinned by the
+ * oracle's restatement only (the reference TUs need the SAMRecord / VariantContext model). */
+typedef struct mgx_read_model {
+    int pcr_rate_factor;            /* PCRErrorModel: 1 HOSTILE, 2 AGGRESSIVE, 3 CONSERVATIVE; 0 = off */
+    int base_quality_threshold;     /* BASE_QUALITY_SCORE_THRESHOLD, 18 */
+    int constant_gcp;               /* gcpHMM, 10; < 0 keeps in->gcp */
+    double log10_mismapping_rate;   /* -4.5 (phredScaledGlobalReadMismappingRate 45); -inf = off */
+    double max_error_per_base;      /* EXPECTED_ERROR_RATE_PER_BASE, 0.02 */
+} mgx_read_model_t;
+void mgx_read_model_defaults(mgx_read_model_t* m);
+int mgx_pairhmm_region(mgx_pairhmm_t* ctx, const mgx_pairhmm_input_t* in, const uint8_t* mapq,
+                       const mgx_read_model_t* model, double* out_log10, uint8_t* out_keep);
+
 /* The two probability tables as built by the product (for table-parity tests):
  * which = 0: ph2pr[128]; which = 1: matchToMatchProb[32640].  Returns the element count. */
 int mgx_pairhmm_table_f32(int which, const float** out);

@@ -16,6 +16,7 @@
  *   intel/pairhmm/avx-pairhmm-template.h:30-62,97-102,110-192,204-345  the M/X/Y recurrence
  *   intel/pairhmm/IntelPairHmm.cc:332-351       float first, < 1e-28f -> double, log10 - const
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -209,3 +210,110 @@ int ph_oracle_batch(int64_t n_pairs, const uint64_t* read_off, const uint8_t* ba
     }
     return used;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Row F2 of SURVEY.md section 8f: the per-read quality model in front of the PairHMM and the
+ * normalisation / filter behind it.  PARITY UNPINNED by a reference build: the translation units
+ * (haplotypecaller/PairHMMLikelihoodCalculationEngine.cpp, utils/variant/GATKVariantContextUtils.cpp,
+ * utils/genotyper/AlleleLikelihoods.h) need the whole SAMRecord / VariantContext model and htslib,
+ * which cannot be built here; the restatement below follows them line by line.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* utils/Utils.cpp:9-17 */
+static int equal_range(const uint8_t* l, int lo, const uint8_t* r, int ro, int n) {
+    for (int i = 0; i < n; i++) if (l[lo + i] != r[ro + i]) return 0;
+    return 1;
+}
+/* utils/variant/GATKVariantContextUtils.cpp:59-100 */
+static int n_repetitions(const uint8_t* unit_full, int unit_off, int unit_len, const uint8_t* test_full,
+                         int test_off, int test_len, int leading) {
+    if (test_len == 0) return 0;
+    int diff = test_len - unit_len, n = 0;
+    if (leading) {
+        for (int s = 0; s <= diff; s += unit_len) {
+            if (equal_range(test_full, s + test_off, unit_full, unit_off, unit_len)) n++; else return n;
+        }
+    } else {
+        for (int s = diff; s >= 0; s -= unit_len) {
+            if (equal_range(test_full, s + test_off, unit_full, unit_off, unit_len)) n++; else return n;
+        }
+    }
+    return n;
+}
+/* PairHMMLikelihoodCalculationEngine.cpp:175-254 */
+static int tandem_repeat_units(const uint8_t* b, int length, int offset) {
+    int maxBW = 0, bw_off = offset, bw_len = 1;
+    for (int str = 1; str <= 8; str++) {
+        if (offset + 1 - str < 0) break;
+        maxBW = n_repetitions(b, offset - str + 1, str, b, 0, offset + 1, 0);
+        if (maxBW > 1) { bw_off = offset - str + 1; bw_len = str; break; }
+    }
+    int maxRL = maxBW;
+    if (offset < length - 1) {
+        int maxFW = 0, fw_off = offset + 1, fw_len = 1;
+        for (int str = 1; str <= 8; str++) {
+            if (offset + str + 1 > length) break;
+            maxFW = n_repetitions(b, offset + 1, str, b, offset + 1, length - offset - 1, 1);
+            if (maxFW > 1) { fw_off = offset + 1; fw_len = str; break; }
+        }
+        if (fw_len == bw_len && memcmp(b + fw_off, b + bw_off, fw_len) == 0) {
+            maxRL = maxFW + maxBW;
+        } else {
+            maxBW = n_repetitions(b, fw_off, fw_len, b, 0, offset + 1, 0);
+            maxRL = maxFW + maxBW;
+        }
+    }
+    if (maxRL > 20) maxRL = 20;
+    return maxRL;
+}
+
+/* modifyReadQualities (:123-147): applyPCRErrorModel (:149-157), capMinimumReadQualities (:256-267),
+ * buildGapContinuationPenalties (:284-292).  Arrays are modified in place; gcp is written. */
+void ph_oracle_read_model(int64_t n_reads, const uint64_t* read_off, const uint8_t* bases, uint8_t* qual,
+                          uint8_t* ins, uint8_t* del, uint8_t* gcp, const uint8_t* mapq, int rate_factor,
+                          int bq_threshold, int constant_gcp) {
+    uint8_t cache[21];
+    for (int i = 0; i <= 20; i++) {      /* :45-61 */
+        double d = 40.0 - exp((double)i / ((double)rate_factor * M_PI));
+        int r = (d > 0.0 ? (int)(d + 0.5) : (int)(d - 0.5)) + 1;
+        cache[i] = (uint8_t)(char)(r > 10 ? r : 10);
+    }
+    for (int64_t r = 0; r < n_reads; r++) {
+        const uint64_t o = read_off[r];
+        const int len = (int)(read_off[r + 1] - o);
+        if (rate_factor > 0)
+            for (int i = 1; i < len; i++) {
+                int rl = tandem_repeat_units(bases + o, len, i - 1);
+                if (cache[rl] < ins[o + i - 1]) ins[o + i - 1] = cache[rl];
+                if (cache[rl] < del[o + i - 1]) del[o + i - 1] = cache[rl];
+            }
+        for (int i = 0; i < len; i++) {
+            int q = qual[o + i];
+            if (mapq[r] < q) q = mapq[r];
+            qual[o + i] = (uint8_t)(q < bq_threshold ? 6 : q);
+            if (ins[o + i] < 6) ins[o + i] = 6;
+            if (del[o + i] < 6) del[o + i] = 6;
+            if (constant_gcp >= 0) gcp[o + i] = (uint8_t)constant_gcp;
+        }
+    }
+}
+
+/* AlleleLikelihoods.h:153-166, 372-391 (normalizeLikelihoods) and :404-419 with
+ * PairHMMLikelihoodCalculationEngine.cpp:294-299 (filterPoorlyModeledEvidence).
+ * io is [read][haplotype]; keep[r] = 0 for reads the filter removes. */
+void ph_oracle_normalize_filter(int64_t n_reads, int64_t n_haps, const uint64_t* read_off, double* io,
+                                double log10_rate, double max_error_per_base, uint8_t* keep) {
+    for (int64_t r = 0; r < n_reads; r++) {
+        double best = -INFINITY;
+        for (int64_t h = 0; h < n_haps; h++) if (io[r * n_haps + h] > best) best = io[r * n_haps + h];
+        if (!isinf(log10_rate) && n_haps > 1) {
+            double cap = best + log10_rate;
+            for (int64_t h = 0; h < n_haps; h++) if (io[r * n_haps + h] < cap) io[r * n_haps + h] = cap;
+        }
+        double len = (double)(read_off[r + 1] - read_off[r]);
+        double max_err = fmin(2.0, ceil(len * max_error_per_base));
+        keep[r] = !(best < max_err * -4.0);
+    }
+}
+
+int ph_oracle_tandem_repeat(const uint8_t* bases, int length, int offset) { return tandem_repeat_units(bases, length, offset); }

@@ -110,3 +110,19 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".inc", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle/" not in txt and "ph_oracle" not in txt and "libpairhmm_oracle" not in txt, f
+
+
+def test_tandem_repeat_known_cases(oracle):
+    """findTandemRepeatUnits on the example its own comment gives
+    (PairHMMLikelihoodCalculationEngine.cpp:233-238: TTCTT(C)CCC is (C)4 at the marked base) and on
+    plain homopolymer / dinucleotide runs."""
+    f = oracle.lib.ph_oracle_tandem_repeat
+    def rl(s, off):
+        b = np.frombuffer(s, dtype=np.uint8)
+        return f(b.ctypes.data_as(ctypes.c_void_p), len(s), off)
+    assert rl(b"TTCTTCCCC", 5) == 4
+    assert rl(b"AAAAAAAAAA", 4) == 10
+    assert rl(b"GAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAC", 10) == 20            # capped at MAX_REPEAT_LENGTH
+    assert rl(b"ACACACACAC", 3) == 5                                       # (AC)2 behind + (AC)3 ahead
+    assert rl(b"ACGT", 1) == 1                                             # no repeat: FW unit G occurs 0 times behind
+    assert rl(b"ACGT", 3) == 1                                             # last base: backward only
