@@ -14,11 +14,16 @@
 #include <cerrno>
 #include <cstdint>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mgx_sortdedup.h"
 #include "mgx_common.h"
+
+extern "C" const char* mgx_last_error(void);
 
 namespace {
 
@@ -110,28 +115,54 @@ extern "C" int mgx_sortdedup_pack(const mgx_raw_records_t* raw, mgx_rec_t* out, 
         return 0;
     };
 
-    std::vector<uint8_t> taken(n, 0);
-    uint64_t k = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        if (taken[i]) continue;
-        taken[i] = 1;
-        uint64_t mate = n;
-        if (!(raw->flag[i] & kIgnorable)) {
-            for (uint64_t q = i + 1; q < n && (taken[q] || same_qname(i, q)); ++q) {
-                if (taken[q]) continue;
-                if (!(raw->flag[q] & kIgnorable)) { mate = q; break; }
+    // The queue logic only ever looks ahead inside one run of equal qnames, so the input can be cut
+    // at qname changes and the pieces packed independently by several threads: the number of records
+    // a piece emits equals the number it consumes, hence arrival slot == input slot of the piece's
+    // first record, and mate indices are piece-local offsets plus that base.
+    auto pack_range = [&](uint64_t lo, uint64_t hi) -> int {
+        std::vector<uint8_t> taken(hi - lo, 0);
+        uint64_t k = lo;
+        for (uint64_t i = lo; i < hi; ++i) {
+            if (taken[i - lo]) continue;
+            taken[i - lo] = 1;
+            uint64_t mate = hi;
+            if (!(raw->flag[i] & kIgnorable)) {
+                for (uint64_t q = i + 1; q < hi && (taken[q - lo] || same_qname(i, q)); ++q) {
+                    if (taken[q - lo]) continue;
+                    if (!(raw->flag[q] & kIgnorable)) { mate = q; break; }
+                }
+            }
+            int rc;
+            if (mate == hi) {
+                if ((rc = emit(k, i, MGX_NO_MATE))) return rc;
+                k += 1;
+            } else {
+                taken[mate - lo] = 1;
+                if ((rc = emit(k, i, (uint32_t)(k + 1)))) return rc;
+                if ((rc = emit(k + 1, mate, (uint32_t)k))) return rc;
+                k += 2;
             }
         }
-        int rc;
-        if (mate == n) {
-            if ((rc = emit(k, i, MGX_NO_MATE))) return rc;
-            k += 1;
-        } else {
-            taken[mate] = 1;
-            if ((rc = emit(k, i, (uint32_t)(k + 1)))) return rc;
-            if ((rc = emit(k + 1, mate, (uint32_t)k))) return rc;
-            k += 2;
-        }
+        return 0;
+    };
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char* e = getenv("MGX_PACK_THREADS")) T = (unsigned)atoi(e);
+    if (T < 1) T = 1;
+    if (T > 64) T = 64;
+    if (n < 200000 || T == 1) return pack_range(0, n);
+    std::vector<uint64_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; ++t) {
+        uint64_t p = n * t / T;
+        while (p < n && p > 0 && same_qname(p - 1, p)) ++p;       // never split a qname group
+        cut[t] = std::max(p, cut[t - 1]);
     }
+    std::vector<int> rcs(T, 0);
+    std::vector<std::string> errs(T);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t)
+        pool.emplace_back([&, t]() { rcs[t] = pack_range(cut[t], cut[t + 1]); if (rcs[t]) errs[t] = mgx_last_error(); });
+    for (auto& th : pool) th.join();
+    for (unsigned t = 0; t < T; ++t) if (rcs[t]) { mgx::set_error("%s", errs[t].c_str()); return rcs[t]; }
     return 0;
 }

@@ -81,3 +81,15 @@ def test_empty_and_tiny(sd_oracle, synth):
     recs, idx, L = sd_oracle.pack(rr.arrays())
     order, dup, _ = sd_oracle.run(L, recs)
     assert order.tolist() == [0] and dup.tolist() == [0]
+
+
+def test_threaded_pack_equals_serial(pkg, sd_oracle, synth, monkeypatch):
+    """Above 200 000 records mgx_sortdedup_pack cuts the input at qname changes and packs the pieces
+    on several threads; the result must be byte-identical to the serial oracle."""
+    raw = synth.gen_sortdedup_raw(101_000, 77, read_len=50, supp_rate=0.1, frag_rate=0.1)
+    assert raw["n_records"] > 200_000
+    orecs, oidx, oL = sd_oracle.pack(raw)
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("MGX_PACK_THREADS", threads)
+        recs, idx, L = pkg.sortdedup.pack(raw)
+        assert L == oL and np.array_equal(idx, oidx) and recs.tobytes() == orecs.tobytes()
