@@ -550,6 +550,7 @@ struct mgx_sortdedup {
     uint8_t* d_dup = nullptr;
     Scalars* d_sc = nullptr;
     void* pinned[2] = {nullptr, nullptr};
+    size_t pinned_cap = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> ev_scatter;    // pairs (start, stop) per scatter launch
@@ -683,10 +684,7 @@ int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out) {
     HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_stop));
     c->ev_scatter.resize(64);
     for (auto& e : c->ev_scatter) HIP_TRY(hipEventCreate(&e));
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipHostMalloc(&c->pinned[i], kPinnedChunk, hipHostMallocDefault));
-        HIP_TRY(hipEventCreate(&c->pin_ev[i]));
-    }
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreate(&c->pin_ev[i]));   // staging buffers: on first upload
     *out = c.release();
     return 0;
 }
@@ -727,10 +725,17 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
     c->packed_pair = L < 0xF0000000ull;      // 5' ends <= L + clip; verified against the device maximum
     // records are streamed through two pinned staging buffers on the copy stream
     const size_t total = (size_t)n_records * sizeof(mgx_rec_t);
+    const size_t chunk = std::min(kPinnedChunk, std::max<size_t>((total + 1) / 2, 1u << 20));
+    if (chunk > c->pinned_cap) {
+        for (int i = 0; i < 2; ++i) { if (c->pinned[i]) (void)hipHostFree(c->pinned[i]); c->pinned[i] = nullptr; }
+        c->pinned_cap = 0;
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&c->pinned[i], chunk, hipHostMallocDefault));
+        c->pinned_cap = chunk;
+    }
     size_t off = 0;
     int buf = 0;
     while (off < total) {
-        const size_t len = std::min(kPinnedChunk, total - off);
+        const size_t len = std::min(c->pinned_cap, total - off);
         HIP_TRY(hipEventSynchronize(c->pin_ev[buf]));
         memcpy(c->pinned[buf], reinterpret_cast<const char*>(recs) + off, len);
         HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c->d_recs) + off, c->pinned[buf], len, hipMemcpyHostToDevice, c->copy));
