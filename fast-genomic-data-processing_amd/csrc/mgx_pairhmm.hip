@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>
@@ -63,8 +64,8 @@ struct mgx_pairhmm {
     int device = 0;
     unsigned flags = 0;
     hipStream_t compute = nullptr, copy = nullptr;
-    float* d_ph2pr_f = nullptr; float* d_mm_f = nullptr;
-    double* d_ph2pr_d = nullptr; double* d_mm_d = nullptr;
+    float* d_ph2pr_f = nullptr; float* d_mm_f = nullptr; float* d_div3_f = nullptr; float* d_ratio_f = nullptr;
+    double* d_ph2pr_d = nullptr; double* d_mm_d = nullptr; double* d_div3_d = nullptr; double* d_ratio_d = nullptr;
     float log10_initial_f = 0; double log10_initial_d = 0;
     int n_cu = 256;
     std::vector<Slab> free_slabs;
@@ -242,6 +243,10 @@ int mgx_pairhmm_create(int device, unsigned flags, mgx_pairhmm_t** out) {
         set_error("no HIP device is visible (this library has no CPU fallback)");
         return -ENODEV;
     }
+    if (device == -1) {                 // MGX_DEVICE_AUTO: contexts are dealt round-robin over the visible GPUs
+        static std::atomic<unsigned> next{0};
+        device = (int)(next.fetch_add(1) % (unsigned)n_dev);
+    }
     if (device < 0 || device >= n_dev) { set_error("device %d out of range (0..%d)", device, n_dev - 1); return -EINVAL; }
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<mgx_pairhmm> c(new (std::nothrow) mgx_pairhmm);
@@ -273,6 +278,10 @@ int mgx_pairhmm_create(int device, unsigned flags, mgx_pairhmm_t** out) {
     if ((rc = upload(&c->d_mm_f, tf.mm.data(), tf.mm.size() * 4, c->compute))) return rc;
     if ((rc = upload(&c->d_ph2pr_d, td.ph2pr.data(), td.ph2pr.size() * 8, c->compute))) return rc;
     if ((rc = upload(&c->d_mm_d, td.mm.data(), td.mm.size() * 8, c->compute))) return rc;
+    if ((rc = upload(&c->d_div3_f, tf.ph2pr_div3.data(), tf.ph2pr_div3.size() * 4, c->compute))) return rc;
+    if ((rc = upload(&c->d_ratio_f, tf.gap_ratio.data(), tf.gap_ratio.size() * 4, c->compute))) return rc;
+    if ((rc = upload(&c->d_div3_d, td.ph2pr_div3.data(), td.ph2pr_div3.size() * 8, c->compute))) return rc;
+    if ((rc = upload(&c->d_ratio_d, td.gap_ratio.data(), td.gap_ratio.size() * 8, c->compute))) return rc;
     c->log10_initial_f = tf.log10_initial;
     c->log10_initial_d = td.log10_initial;
     HIP_TRY(hipStreamSynchronize(c->compute));
@@ -285,6 +294,7 @@ void mgx_pairhmm_destroy(mgx_pairhmm_t* c) {
     (void)hipSetDevice(c->device);
     (void)hipFree(c->d_ph2pr_f); (void)hipFree(c->d_mm_f);
     (void)hipFree(c->d_ph2pr_d); (void)hipFree(c->d_mm_d);
+    (void)hipFree(c->d_div3_f); (void)hipFree(c->d_ratio_f); (void)hipFree(c->d_div3_d); (void)hipFree(c->d_ratio_d);
     for (auto& sl : c->free_slabs) { (void)hipFree(sl.dev); if (sl.pin) (void)hipHostFree(sl.pin); }
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -608,7 +618,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         a.log10_initial_d = c->log10_initial_d;
         if (!force_f64) {
             a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count;
-            a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f;
+            a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f; a.ph2pr_div3 = c->d_div3_f; a.gap_ratio = c->d_ratio_f;
             KernelFn f = pick_kernel<float>(bin.G, bin.RPL);
             if (!f) { set_error("no fp32 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 0], s));
@@ -616,7 +626,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 1], s));
         }
         {
-            a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d;
+            a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d; a.ph2pr_div3 = c->d_div3_d; a.gap_ratio = c->d_ratio_d;
             if (force_f64) { a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count; }
             else { a.job_list = b->d_rerun_list + bin.job_begin; a.n_dyn = b->d_rerun_count + k; a.n_static = 0; }
             KernelFn f = pick_kernel<double>(bin.Gd, bin.RPLd);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
@@ -264,13 +265,27 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ k
 
     // phase 1: stable rank of every key inside its wavefront's 1024-key slice
     u64 key[kItems];
+    u64 pay[HAS_P64 ? kItems : 1];
     u32 lrank[kItems];
     const u64 lt = lanemask_lt();
+    // all global loads of the tile are issued up front: the payload's HBM latency is then hidden
+    // behind the ranking arithmetic instead of being exposed between two barriers later on
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const u32 li = wave * (kTile / 4) + k * 64 + lane;      // local index: slices are contiguous per wave
+        key[k] = li < tile_n ? kin[tile0 + li] : ~0ull;
+    }
+    if constexpr (HAS_P64) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const u32 li = wave * (kTile / 4) + k * 64 + lane;
+            pay[k] = li < tile_n ? pin64[tile0 + li] : 0ull;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const u32 li = wave * (kTile / 4) + k * 64 + lane;
         const bool valid = li < tile_n;
-        key[k] = valid ? kin[tile0 + li] : ~0ull;
         const u32 d = (u32)(key[k] >> shift) & 255u;
         u64 peers = __ballot(valid);
 #pragma unroll
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ k
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const u32 li = wave * (kTile / 4) + k * 64 + lane;
-            if (li < tile_n) sbuf[lpos[k]] = pin64[tile0 + li];
+            if (li < tile_n) sbuf[lpos[k]] = pay[k];
         }
         __syncthreads();
 #pragma unroll
@@ -656,6 +671,10 @@ int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out) {
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
         set_error("no HIP device is visible (this library has no CPU fallback)");
         return -ENODEV;
+    }
+    if (device == -1) {                 // MGX_DEVICE_AUTO: contexts are dealt round-robin over the visible GPUs
+        static std::atomic<unsigned> next{0};
+        device = (int)(next.fetch_add(1) % (unsigned)n_dev);
     }
     if (device < 0 || device >= n_dev) { set_error("device %d out of range", device); return -EINVAL; }
     HIP_TRY(hipSetDevice(device));

@@ -67,6 +67,12 @@ const Tables<float>& tables<float>() {
         Builder<float>().build(t);
         t.ph2pr.resize(kPh2prSize);
         for (int x = 0; x < kPh2prSize; ++x) t.ph2pr[x] = powf(10.f, -float(x) / 10.f);
+        t.ph2pr_div3.resize(kPh2prSize); t.gap_ratio.resize(kPh2prSize);
+        for (int x = 0; x < kPh2prSize; ++x) {
+            t.ph2pr_div3[x] = t.ph2pr[x] / 3.0f;                                   // VEC_DIV(distm, 3), avx-pairhmm-template.h:150
+            const float g = 1.0f - t.ph2pr[x];
+            t.gap_ratio[x] = g != 0.0f ? t.ph2pr[x] / g : 0.0f;
+        }
         t.initial = ldexpf(1.f, 120);
         t.log10_initial = log10f(t.initial);
     });
@@ -81,6 +87,12 @@ const Tables<double>& tables<double>() {
         Builder<double>().build(t);
         t.ph2pr.resize(kPh2prSize);
         for (int x = 0; x < kPh2prSize; ++x) t.ph2pr[x] = std::pow(10.0, -double(x) / 10.0);
+        t.ph2pr_div3.resize(kPh2prSize); t.gap_ratio.resize(kPh2prSize);
+        for (int x = 0; x < kPh2prSize; ++x) {
+            t.ph2pr_div3[x] = t.ph2pr[x] / 3.0;
+            const double g = 1.0 - t.ph2pr[x];
+            t.gap_ratio[x] = g != 0.0 ? t.ph2pr[x] / g : 0.0;
+        }
         t.initial = std::ldexp(1.0, 1020);
         t.log10_initial = std::log10(t.initial);
     });

@@ -11,6 +11,8 @@ template <typename T>
 struct Tables {
     std::vector<T> ph2pr;  // [128]
     std::vector<T> mm;     // [32640] triangular matchToMatchProb
+    std::vector<T> ph2pr_div3;  // [128] ph2pr / 3
+    std::vector<T> gap_ratio;   // [128] ph2pr / (1 - ph2pr)
     T initial;             // 2^120 (float) / 2^1020 (double), Context.h:142,183
     T log10_initial;
 };

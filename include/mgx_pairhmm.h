@@ -89,7 +89,11 @@ typedef struct mgx_pairhmm_stats {
 
 const char* mgx_last_error(void);
 
-/* device: HIP device ordinal.  Builds the Context<float>/Context<double> tables
+#define MGX_DEVICE_AUTO (-1)   /* device argument of the create functions: next GPU, round-robin per process */
+
+/* device: HIP device ordinal or MGX_DEVICE_AUTO (one context per worker thread then spreads the
+ * threads over the GPUs of the node -- the host work queue of the reference's threadFunc,
+ * main.cpp:254, needs nothing else).  Builds the Context<float>/Context<double> tables
  * (intel/pairhmm/Context.h) on the host and uploads them. */
 int mgx_pairhmm_create(int device, unsigned flags, mgx_pairhmm_t** out);
 void mgx_pairhmm_destroy(mgx_pairhmm_t* ctx);
