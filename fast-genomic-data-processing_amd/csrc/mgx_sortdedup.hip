@@ -53,10 +53,12 @@ constexpr u32 kIgnorable = 0x4 | 0x100 | 0x800;
 constexpr int kWalkCap = 64;                          // longest run a single lane walks
 
 struct Scalars {            // device-side scalars, one 64-byte read-back
-    u64 max_coord, max_k1d, max_k2d, max_k1s;
-    u32 n_double, n_single, n_long_d, n_long_s;
-    u32 n_dup, bad_mate, pad_[2];   // bad_mate: a record names a mate index outside the shard
+    u64 max_coord, max_k1d, max_k2d, max_k1s, max_near;
+    u32 n_double, n_single, n_long_d, n_long_s;    // n_double: "far" double pairs (two-word keys)
+    u32 n_dup, bad_mate, n_near, n_long_n;         // bad_mate: a record names a mate index outside the shard
+    u32 pad_[2];
 };
+constexpr u64 kNearSpan = 65536;       // near pair: mate 5' end less than this beyond record 1's
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
@@ -100,47 +102,55 @@ struct BuildOut {
     u64 L;
     int packed_coord;                     // ckey = coord << 32 | i (every coordinate < 2^32)
     int packed_pair;                      // dk2 = mate 5' end << 32 | record (every 5' end < 2^32)
+    u64* nk; u32* nrec;                   // near double pairs: one key word p1 << 18 | orient << 16 | (p2 - p1)
+    int near_enabled;
 };
 
 // Entries are compacted with one global atomic per wavefront and kind, so their order is not the
 // arrival order; nothing downstream depends on it: runs are formed by key equality and total ties
 // between entries are broken by the record index itself (k_mark_runs), not by position.
 __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n, BuildOut o, Scalars* sc) {
-    __shared__ u64 smax[4][4];
-    __shared__ u32 s_cnt[2], s_base[2];
+    __shared__ u64 smax[4][5];
+    __shared__ u32 s_cnt[3], s_base[3];
     const u32 base = blockIdx.x * kBuildBlock;
     const u64 lt = lanemask_lt();
     // pass A: how many entries of each kind does this block produce -> ONE global atomic per kind
     // (a single counter word sustains only ~90 atomics/us: never one per wavefront)
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     {
-        u32 cd = 0, cs = 0;
+        u32 cd = 0, cs = 0, cn = 0;
         for (int k = 0; k < kBuildBlock / 256; ++k) {
             const u32 i = base + k * 256 + threadIdx.x;
             if (i < n) {
                 // classify() needs flag and mate only: bytes 16..21 of the 32-byte record
                 const u32 mate = recs[i].mate; const u32 flag = recs[i].flag;
-                const int c = ((flag & kIgnorable) || (mate != MGX_NO_MATE && mate >= n)) ? 0 : (mate == MGX_NO_MATE ? 2 : (mate > i ? 1 : 0));
-                cd += c == 1; cs += c == 2;
+                int c = ((flag & kIgnorable) || (mate != MGX_NO_MATE && mate >= n)) ? 0 : (mate == MGX_NO_MATE ? 2 : (mate > i ? 1 : 0));
+                if (c == 1 && o.near_enabled) {
+                    const u64 a5 = recs[i].prime5, b5 = recs[mate].prime5;
+                    if ((a5 > b5 ? a5 - b5 : b5 - a5) < kNearSpan) c = 3;
+                }
+                cd += c == 1; cs += c == 2; cn += c == 3;
             }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { cd += __shfl_xor(cd, off, 64); cs += __shfl_xor(cs, off, 64); }
-        if ((threadIdx.x & 63) == 0) { if (cd) atomicAdd(&s_cnt[0], cd); if (cs) atomicAdd(&s_cnt[1], cs); }
+        for (int off = 32; off > 0; off >>= 1) { cd += __shfl_xor(cd, off, 64); cs += __shfl_xor(cs, off, 64); cn += __shfl_xor(cn, off, 64); }
+        if ((threadIdx.x & 63) == 0) { if (cd) atomicAdd(&s_cnt[0], cd); if (cs) atomicAdd(&s_cnt[1], cs); if (cn) atomicAdd(&s_cnt[2], cn); }
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         const u32 cnt = s_cnt[threadIdx.x];
-        s_base[threadIdx.x] = cnt ? atomicAdd(threadIdx.x == 0 ? &sc->n_double : &sc->n_single, cnt) : 0u;
+        u32* dst = threadIdx.x == 0 ? &sc->n_double : threadIdx.x == 1 ? &sc->n_single : &sc->n_near;
+        s_base[threadIdx.x] = cnt ? atomicAdd(dst, cnt) : 0u;
         s_cnt[threadIdx.x] = 0;                 // reused below as the block-local running offset
     }
     __syncthreads();
-    u64 m_coord = 0, m_k1d = 0, m_k2d = 0, m_k1s = 0;
+    u64 m_coord = 0, m_k1d = 0, m_k2d = 0, m_k1s = 0, m_near = 0;
     for (int k = 0; k < kBuildBlock / 256; ++k) {
         const u32 i = base + k * 256 + threadIdx.x;
         int c = 0;
         mgx_rec_t r;
+        u64 p1 = 0, p2 = 0; u32 orient = 0;
         if (i < n) {
             r = recs[i];
             if (r.mate != MGX_NO_MATE && r.mate >= n) { sc->bad_mate = 1; r.mate = MGX_NO_MATE; r.flag |= (uint16_t)kIgnorable; }
@@ -148,27 +158,37 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
             o.ckey[i] = o.packed_coord ? ((u64)r.coord << 32) | i : (u64)r.coord;
             if (!o.packed_coord) o.cval[i] = i;
             m_coord = max(m_coord, (u64)r.coord);
+            if (c == 1) {
+                // DoublePair::DoublePair, pair.cpp:71-108
+                const mgx_rec_t m = recs[r.mate];
+                p1 = r.prime5; p2 = m.prime5;
+                bool f1 = !(r.flag & 0x10), f2 = !(m.flag & 0x10);
+                if (p1 > p2) { const u64 t = p1; p1 = p2; p2 = t; const bool tf = f1; f1 = f2; f2 = tf; }
+                orient = f1 ? (f2 ? 0u : 1u) : (f2 ? 2u : 3u);       // FF FR RF RR
+                if (p1 == p2 && orient == 2u) orient = 1u;
+                if (o.near_enabled && p2 - p1 < kNearSpan) c = 3;
+            }
         }
-        const u64 bd = __ballot(c == 1), bs = __ballot(c == 2);
-        u32 based = 0, bases = 0;
+        const u64 bd = __ballot(c == 1), bs = __ballot(c == 2), bn = __ballot(c == 3);
+        u32 based = 0, bases = 0, basen = 0;
         if ((threadIdx.x & 63) == 0) {
             if (bd) based = atomicAdd(&s_cnt[0], (u32)__popcll(bd));      // LDS
             if (bs) bases = atomicAdd(&s_cnt[1], (u32)__popcll(bs));
+            if (bn) basen = atomicAdd(&s_cnt[2], (u32)__popcll(bn));
         }
-        based = __shfl(based, 0, 64) + s_base[0]; bases = __shfl(bases, 0, 64) + s_base[1];
-        if (c == 1) {
-            // DoublePair::DoublePair, pair.cpp:71-108
-            const mgx_rec_t m = recs[r.mate];
-            u64 p1 = r.prime5, p2 = m.prime5;
-            bool f1 = !(r.flag & 0x10), f2 = !(m.flag & 0x10);
-            if (p1 > p2) { const u64 t = p1; p1 = p2; p2 = t; const bool tf = f1; f1 = f2; f2 = tf; }
-            u32 orient = f1 ? (f2 ? 0u : 1u) : (f2 ? 2u : 3u);       // FF FR RF RR
-            if (p1 == p2 && orient == 2u) orient = 1u;
+        based = __shfl(based, 0, 64) + s_base[0]; bases = __shfl(bases, 0, 64) + s_base[1]; basen = __shfl(basen, 0, 64) + s_base[2];
+        if (c == 1 || c == 3) { m_k1d = max(m_k1d, (p1 << 2) + orient); m_k2d = max(m_k2d, p2); }
+        if (c == 3) {
+            // near pair: the whole (sort_key, mate end) identity fits one word, injectively
+            const u64 key = (p1 << 18) | ((u64)orient << 16) | (p2 - p1);
+            const u32 at = basen + (u32)__popcll(bn & lt);
+            o.nk[at] = key; o.nrec[at] = i;
+            m_near = max(m_near, key);
+        } else if (c == 1) {
             const u64 k1 = (p1 << 2) + orient;
             const u32 at = based + (u32)__popcll(bd & lt);
             o.dk1[at] = k1;
             if (o.packed_pair) o.dk2[at] = (p2 << 32) | i; else { o.dk2[at] = p2; o.drec[at] = i; }
-            m_k1d = max(m_k1d, k1); m_k2d = max(m_k2d, p2);
         } else if (c == 2) {
             // SinglePair::SinglePair, pair.cpp:51-69
             const u64 k1 = (r.prime5 << 2) + ((r.flag & 0x10) ? 3u : 0u);
@@ -185,13 +205,15 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
         m_k1d = max(m_k1d, (u64)__shfl_xor(m_k1d, off, 64));
         m_k2d = max(m_k2d, (u64)__shfl_xor(m_k2d, off, 64));
         m_k1s = max(m_k1s, (u64)__shfl_xor(m_k1s, off, 64));
+        m_near = max(m_near, (u64)__shfl_xor(m_near, off, 64));
     }
-    if (lane == 0) { smax[wave][0] = m_coord; smax[wave][1] = m_k1d; smax[wave][2] = m_k2d; smax[wave][3] = m_k1s; }
+    if (lane == 0) { smax[wave][0] = m_coord; smax[wave][1] = m_k1d; smax[wave][2] = m_k2d; smax[wave][3] = m_k1s; smax[wave][4] = m_near; }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 5) {
         const u64 v = max(max(smax[0][threadIdx.x], smax[1][threadIdx.x]), max(smax[2][threadIdx.x], smax[3][threadIdx.x]));
-        u64* dst = threadIdx.x == 0 ? &sc->max_coord : threadIdx.x == 1 ? &sc->max_k1d : threadIdx.x == 2 ? &sc->max_k2d : &sc->max_k1s;
-        atomicMax(dst, v);
+        u64* dst = threadIdx.x == 0 ? &sc->max_coord : threadIdx.x == 1 ? &sc->max_k1d : threadIdx.x == 2 ? &sc->max_k2d
+                 : threadIdx.x == 3 ? &sc->max_k1s : &sc->max_near;
+        if (v) atomicMax(dst, v);
     }
 }
 
@@ -393,7 +415,7 @@ __global__ __launch_bounds__(256) void k_set_indicator(const u64* __restrict__ k
 // slice of the sorted entries by binary search, sets bits in LDS and writes whole words with plain
 // coalesced stores.  No global atomics and no memset of the 4L-bit map.
 constexpr u32 kIndTile = 65536;              // positions per workgroup (2 x 8 KB of LDS)
-template <int END, bool PK>
+template <int END, bool PK, bool DEFINE>
 __global__ __launch_bounds__(256) void k_indicator_tiles(const u64* __restrict__ k1, const u64* __restrict__ k2, u32 n,
                                                          u32* __restrict__ indicator, u64 Lp) {
     __shared__ u32 fw[kIndTile / 32], rv[kIndTile / 32];
@@ -419,9 +441,58 @@ __global__ __launch_bounds__(256) void k_indicator_tiles(const u64* __restrict__
     u32* gf = indicator + (size_t)blockIdx.x * (kIndTile / 32);
     u32* gr = indicator + (size_t)(Lp >> 5) + (size_t)blockIdx.x * (kIndTile / 32);
     for (u32 w = threadIdx.x; w < kIndTile / 32; w += 256) {
-        if (END == 2) { gf[w] = fw[w]; gr[w] = rv[w]; }                       // first pass: defines every word
-        else { if (fw[w]) gf[w] |= fw[w]; if (rv[w]) gr[w] |= rv[w]; }        // second pass: this tile owns them
+        if (DEFINE) { gf[w] = fw[w]; gr[w] = rv[w]; }                         // first pass: defines every word
+        else { if (fw[w]) gf[w] |= fw[w]; if (rv[w]) gr[w] |= rv[w]; }        // later passes: this tile owns them
     }
+}
+
+// Near pairs (one key word p1 << 18 | orient << 16 | delta, sorted): both ends of every pair in ONE
+// pass.  A pair's record-1 end lies in the tile of p1, its record-2 end at p1 + delta < p1 + 65536 in
+// that tile or the next, so tile t scans the entries with p1 in [t*65536 - 65535, (t+1)*65536).
+// Always the first pass over the bitmap: defines every word.
+__global__ __launch_bounds__(256) void k_indicator_tiles_near(const u64* __restrict__ nk, u32 n, u32* __restrict__ indicator, u64 Lp) {
+    __shared__ u32 fw[kIndTile / 32], rv[kIndTile / 32];
+    __shared__ u32 s_lo, s_hi;
+    for (u32 w = threadIdx.x; w < kIndTile / 32; w += 256) { fw[w] = 0; rv[w] = 0; }
+    const u64 pos_lo = (u64)blockIdx.x * kIndTile, pos_hi = pos_lo + kIndTile;
+    if (threadIdx.x < 2) {
+        const u64 target = threadIdx.x == 0 ? (pos_lo >= kNearSpan - 1 ? pos_lo - (kNearSpan - 1) : 0ull) : pos_hi;
+        u32 a = 0, b = n;
+        while (a < b) { const u32 m = a + (b - a) / 2; if ((nk[m] >> 18) < target) a = m + 1; else b = m; }
+        if (threadIdx.x == 0) s_lo = a; else s_hi = a;
+    }
+    __syncthreads();
+    const u32 lo = s_lo, hi = s_hi;
+    for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
+        const u64 key = nk[i];
+        const u64 p1 = key >> 18, p2 = p1 + (key & 0xFFFFull);
+        const u32 orient = (u32)(key >> 16) & 3u;
+        if (p1 >= pos_lo) {                                  // record 1 forward: FF, FR
+            const u32 p = (u32)(p1 - pos_lo);
+            atomicOr((orient == 0u || orient == 1u) ? &fw[p >> 5] : &rv[p >> 5], 1u << (p & 31));
+        }
+        if (p2 >= pos_lo && p2 < pos_hi) {                   // record 2 forward: FF, RF
+            const u32 p = (u32)(p2 - pos_lo);
+            atomicOr((orient == 0u || orient == 2u) ? &fw[p >> 5] : &rv[p >> 5], 1u << (p & 31));
+        }
+    }
+    __syncthreads();
+    u32* gf = indicator + (size_t)blockIdx.x * (kIndTile / 32);
+    u32* gr = indicator + (size_t)(Lp >> 5) + (size_t)blockIdx.x * (kIndTile / 32);
+    for (u32 w = threadIdx.x; w < kIndTile / 32; w += 256) { gf[w] = fw[w]; gr[w] = rv[w]; }
+}
+
+// atomic fallback for near pairs (reference bitmap layout)
+__global__ __launch_bounds__(256) void k_set_indicator_near(const u64* __restrict__ nk, u32 n, u32* __restrict__ indicator,
+                                                            u64 indicator_bits, u64 L) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = nk[i];
+    const u64 p1 = key >> 18, p2 = p1 + (key & 0xFFFFull);
+    const u32 orient = (u32)(key >> 16) & 3u;
+    const u64 b1 = p1 + ((orient == 0u || orient == 1u) ? 0ull : L), b2 = p2 + ((orient == 0u || orient == 2u) ? 0ull : L);
+    if (b1 < indicator_bits) atomicOr(&indicator[b1 >> 5], 1u << (b1 & 31));
+    if (b2 < indicator_bits) atomicOr(&indicator[b2 >> 5], 1u << (b2 & 31));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -450,7 +521,8 @@ __global__ __launch_bounds__(256) void k_mark_runs(const u64* __restrict__ k1, c
                                                    uint8_t* __restrict__ dup, u32* __restrict__ long_list, u32* n_long) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    auto K2 = [&](u32 t) -> u64 { return !DOUBLE ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
+    // near pairs come as DOUBLE with k2 == nullptr: the single key word is the whole identity
+    auto K2 = [&](u32 t) -> u64 { return (!DOUBLE || !k2) ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
     auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
     const u64 a1 = k1[i], a2 = K2(i);
     if (i > 0 && k1[i - 1] == a1 && (!DOUBLE || K2(i - 1) == a2)) return;      // not a run head
@@ -488,7 +560,7 @@ __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, c
     __shared__ u32 sp[256];
     __shared__ u32 sr[256];
     __shared__ u32 s_end;
-    auto K2 = [&](u32 t) -> u64 { return !DOUBLE ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
+    auto K2 = [&](u32 t) -> u64 { return (!DOUBLE || !k2) ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
     auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
     for (u32 li = blockIdx.x; li < *n_long; li += gridDim.x) {
         const u32 i = long_list[li];
@@ -560,6 +632,7 @@ struct mgx_sortdedup {
     u64 *d_ckey[2] = {nullptr, nullptr}; u32* d_cval[2] = {nullptr, nullptr};
     u64 *d_k1[2] = {nullptr, nullptr}, *d_k2[2] = {nullptr, nullptr}; u32* d_prec[2] = {nullptr, nullptr};
     u64* d_sk1[2] = {nullptr, nullptr}; u32* d_srec[2] = {nullptr, nullptr};
+    u64* d_nk[2] = {nullptr, nullptr}; u32* d_nrec[2] = {nullptr, nullptr};     // near double pairs
     u32 *d_hist = nullptr, *d_chunk = nullptr, *d_long = nullptr;
     u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
     uint8_t* d_dup = nullptr;
@@ -588,6 +661,7 @@ void free_buffers(mgx_sortdedup* c) {
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(c->d_ckey[i]); (void)hipFree(c->d_cval[i]); (void)hipFree(c->d_k1[i]); (void)hipFree(c->d_k2[i]);
         (void)hipFree(c->d_prec[i]); (void)hipFree(c->d_sk1[i]); (void)hipFree(c->d_srec[i]);
+        (void)hipFree(c->d_nk[i]); (void)hipFree(c->d_nrec[i]); c->d_nk[i] = nullptr; c->d_nrec[i] = nullptr;
         c->d_ckey[i] = c->d_k1[i] = c->d_k2[i] = c->d_sk1[i] = nullptr;
         c->d_cval[i] = c->d_prec[i] = c->d_srec[i] = nullptr;
     }
@@ -614,6 +688,7 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
         rc |= dalloc(&c->d_ckey[i], n); rc |= dalloc(&c->d_cval[i], n);
         rc |= dalloc(&c->d_k1[i], half); rc |= dalloc(&c->d_k2[i], half); rc |= dalloc(&c->d_prec[i], half);
         rc |= dalloc(&c->d_sk1[i], n); rc |= dalloc(&c->d_srec[i], n);
+        rc |= dalloc(&c->d_nk[i], half); rc |= dalloc(&c->d_nrec[i], half);
     }
     rc |= dalloc(&c->d_hist, n_tiles * 256);
     rc |= dalloc(&c->d_chunk, ((n_tiles + kChunkTiles - 1) / kChunkTiles + 1) * 256);
@@ -780,7 +855,8 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
             HIP_TRY(hipMemsetAsync(c->d_dup, 0, n, s));
             const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
             BuildOut o{c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
-                       c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0, c->packed_pair ? 1 : 0};
+                       c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0, c->packed_pair ? 1 : 0,
+                       c->d_nk[0], c->d_nrec[0], c->packed_pair ? 1 : 0};
             hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, o, c->d_sc);
             HIP_TRY(hipGetLastError());
         }
@@ -797,8 +873,8 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         break;
     }
     if (c->sc.bad_mate) { set_error("a record's mate index is outside the uploaded shard"); return -EINVAL; }
-    const u32 nd = c->sc.n_double, ns = c->sc.n_single;
-    c->stats.n_double = nd; c->stats.n_single = ns;
+    const u32 nd = c->sc.n_double, ns = c->sc.n_single, nn = c->sc.n_near;   // nd: far pairs only
+    c->stats.n_double = (uint64_t)nd + nn; c->stats.n_single = ns;
     c->stats.key_bits_coord = bits_of(c->sc.max_coord);
     c->stats.key_bits_pair1 = bits_of(std::max<uint64_t>(c->sc.max_k1d, c->sc.max_k1s));
     c->stats.key_bits_pair2 = bits_of(c->sc.max_k2d);
@@ -813,7 +889,28 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     const u32 n_ind_tiles = (u32)((c->L + kIndTile - 1) / kIndTile);
     if (!tiled && n) HIP_TRY(hipMemsetAsync(c->d_indicator, 0, (size_t)((c->indicator_bits + 64 + 31) / 32) * 4, s));
 
-    // doubles: LSD over (sort_key, mate 5' end): sort by the mate end first, then by sort_key.
+    // near double pairs (mate 5' end within 65 535 of record 1's -- every proper pair): the whole
+    // (sort_key, mate end) identity is ONE injective key word p1 << 18 | orient << 16 | delta, so one
+    // LSD sort of (8-byte key, 4-byte record) groups equal pairs: 7 passes x 12 B instead of 9 x 16 B.
+    // Runs only need equal keys to be adjacent, not the reference's exact order.
+    int ncur = 0;
+    if ((rc = radix_sort(c, c->d_nk, nullptr, c->d_nrec, nn, 0, bits_of(c->sc.max_near), &ncur))) return rc;
+    bool defined = false;                     // has a pass already written every word of the tiled bitmap?
+    if (tiled && n && c->packed_pair) {
+        hipLaunchKernelGGL(k_indicator_tiles_near, dim3(n_ind_tiles), dim3(256), 0, s, c->d_nk[ncur], nn, c->d_indicator, Lp);
+        defined = true;
+    } else if (!tiled && nn) {
+        hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, s, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
+    }
+    if (nn) {
+        hipLaunchKernelGGL((k_mark_runs<true, false>), dim3((nn + 255) / 256), dim3(256), 0, s, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_n);
+        hipLaunchKernelGGL((k_mark_long<true, false>), dim3(c->n_cu * 2), dim3(256), 0, s, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_n);
+    }
+
+    // far double pairs (discordant, cross-contig, or every pair when keys are wider than 32 bits):
+    // LSD over (sort_key, mate 5' end): sort by the mate end first, then by sort_key.
     // Packed form: two 8-byte arrays per entry -- sort_key and (mate end << 32 | record) -- take
     // turns as key and payload (16 B per entry per pass, two LDS exchange rounds instead of three).
     int cur = 0;
@@ -823,10 +920,17 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     } else {
         if ((rc = radix_sort(c, c->d_k2, c->d_k1, c->d_prec, nd, 0, bits_of(c->sc.max_k2d), &cur))) return rc;
     }
-    if (tiled && n) {
-        if (pk) hipLaunchKernelGGL((k_indicator_tiles<2, true>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
-        else    hipLaunchKernelGGL((k_indicator_tiles<2, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
-    } else if (nd) {
+    if (tiled && n && (nd || !defined)) {
+        const dim3 gt(n_ind_tiles);
+        if (defined) {
+            if (pk) hipLaunchKernelGGL((k_indicator_tiles<2, true, false>), gt, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+            else    hipLaunchKernelGGL((k_indicator_tiles<2, false, false>), gt, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+        } else {
+            if (pk) hipLaunchKernelGGL((k_indicator_tiles<2, true, true>), gt, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+            else    hipLaunchKernelGGL((k_indicator_tiles<2, false, true>), gt, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+            defined = true;
+        }
+    } else if (!tiled && nd) {
         if (pk) hipLaunchKernelGGL((k_set_indicator<2, true>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
         else    hipLaunchKernelGGL((k_set_indicator<2, false>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
     }
@@ -834,8 +938,8 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     if (nd) {
         const dim3 g((nd + 255) / 256), gl(c->n_cu * 2);
         if (tiled) {
-            if (pk) hipLaunchKernelGGL((k_indicator_tiles<1, true>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
-            else    hipLaunchKernelGGL((k_indicator_tiles<1, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+            if (pk) hipLaunchKernelGGL((k_indicator_tiles<1, true, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
+            else    hipLaunchKernelGGL((k_indicator_tiles<1, false, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
         } else {
             if (pk) hipLaunchKernelGGL((k_set_indicator<1, true>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
             else    hipLaunchKernelGGL((k_set_indicator<1, false>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
