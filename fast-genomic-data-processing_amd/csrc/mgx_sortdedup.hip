@@ -20,6 +20,7 @@
 #include <atomic>
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -526,11 +527,14 @@ __global__ __launch_bounds__(256) void k_mark_runs(const u64* __restrict__ k1, c
     auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
     const u64 a1 = k1[i], a2 = K2(i);
     if (i > 0 && k1[i - 1] == a1 && (!DOUBLE || K2(i - 1) == a2)) return;      // not a run head
+    // a run of one entry (nine runs in ten) needs no quality at all: the records are only gathered
+    // once a second entry with the same key shows up
     u32 best = i;
-    u64 bq = DOUBLE ? quality_double(recs, REC(i)) : quality_single(recs, REC(i));
+    u64 bq = 0;
     u32 j = i + 1;
     for (; j < n && j - i < kWalkCap; ++j) {
         if (k1[j] != a1 || (DOUBLE && K2(j) != a2)) break;
+        if (j == i + 1) bq = DOUBLE ? quality_double(recs, REC(i)) : quality_single(recs, REC(i));
         const u64 q = DOUBLE ? quality_double(recs, REC(j)) : quality_single(recs, REC(j));
         if (q < bq || (q == bq && REC(j) < REC(best))) { bq = q; best = j; }
     }
@@ -633,7 +637,11 @@ struct mgx_sortdedup {
     u64 *d_k1[2] = {nullptr, nullptr}, *d_k2[2] = {nullptr, nullptr}; u32* d_prec[2] = {nullptr, nullptr};
     u64* d_sk1[2] = {nullptr, nullptr}; u32* d_srec[2] = {nullptr, nullptr};
     u64* d_nk[2] = {nullptr, nullptr}; u32* d_nrec[2] = {nullptr, nullptr};     // near double pairs
-    u32 *d_hist = nullptr, *d_chunk = nullptr, *d_long = nullptr;
+    // three independent sorts run concurrently (main: far pairs + singles, side[0]: near pairs,
+    // side[1]: records), each with its own histogram / scan / long-run scratch
+    struct Scratch { u32 *hist = nullptr, *chunk = nullptr, *longl = nullptr; } scr[3];
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_ind = nullptr, ev_side[2] = {nullptr, nullptr};
     u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
     uint8_t* d_dup = nullptr;
     Scalars* d_sc = nullptr;
@@ -665,9 +673,8 @@ void free_buffers(mgx_sortdedup* c) {
         c->d_ckey[i] = c->d_k1[i] = c->d_k2[i] = c->d_sk1[i] = nullptr;
         c->d_cval[i] = c->d_prec[i] = c->d_srec[i] = nullptr;
     }
-    (void)hipFree(c->d_hist); (void)hipFree(c->d_chunk);
-    (void)hipFree(c->d_long); (void)hipFree(c->d_dup);
-    c->d_hist = c->d_chunk = c->d_long = nullptr; c->d_dup = nullptr;
+    for (auto& q : c->scr) { (void)hipFree(q.hist); (void)hipFree(q.chunk); (void)hipFree(q.longl); q.hist = q.chunk = q.longl = nullptr; }
+    (void)hipFree(c->d_dup); c->d_dup = nullptr;
     c->cap = 0;
 }
 
@@ -690,9 +697,11 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
         rc |= dalloc(&c->d_sk1[i], n); rc |= dalloc(&c->d_srec[i], n);
         rc |= dalloc(&c->d_nk[i], half); rc |= dalloc(&c->d_nrec[i], half);
     }
-    rc |= dalloc(&c->d_hist, n_tiles * 256);
-    rc |= dalloc(&c->d_chunk, ((n_tiles + kChunkTiles - 1) / kChunkTiles + 1) * 256);
-    rc |= dalloc(&c->d_long, n / kWalkCap + 16);
+    for (auto& q : c->scr) {
+        rc |= dalloc(&q.hist, n_tiles * 256);
+        rc |= dalloc(&q.chunk, ((n_tiles + kChunkTiles - 1) / kChunkTiles + 1) * 256);
+        rc |= dalloc(&q.longl, n / kWalkCap + 16);
+    }
     rc |= dalloc(&c->d_dup, n);
     if (rc) { free_buffers(c); return -ENOMEM; }
     c->cap = n;
@@ -701,31 +710,31 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
 
 // one stable LSD radix sort of (key, [p64], p32) over `bits` low bits of the key
 // buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
-int radix_sort(mgx_sortdedup* c, u64* key[2], u64* p64[2], u32* p32[2], u32 n, int first_shift, int bits, int* cur) {
+int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q, u64* key[2], u64* p64[2], u32* p32[2], u32 n,
+               int first_shift, int bits, int* cur) {
     if (n == 0) return 0;
     const u32 n_tiles = (n + kTile - 1) / kTile;
     const u32 n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
-    hipStream_t s = c->compute;
     for (int shift = first_shift; shift < first_shift + bits; shift += 8) {
         const int in = *cur, out = in ^ 1;
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, c->d_hist);
-        hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, c->d_hist, n_tiles, c->d_chunk);
-        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, s, c->d_chunk, n_chunks);
-        hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, c->d_hist, n_tiles, c->d_chunk);
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, q.hist);
+        hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
+        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, s, q.chunk, n_chunks);
+        hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
         const bool timing = c->ev_used + 2 <= c->ev_scatter.size();
         if (timing) HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used], s));
         if (p64 && !p32)
             hipLaunchKernelGGL((k_radix_scatter<true, false>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
-                               (const u32*)nullptr, (u32*)nullptr, n, shift, c->d_hist);
+                               (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist);
         else if (p64)
             hipLaunchKernelGGL((k_radix_scatter<true, true>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
-                               p32[in], p32[out], n, shift, c->d_hist);
+                               p32[in], p32[out], n, shift, q.hist);
         else if (p32)
             hipLaunchKernelGGL((k_radix_scatter<false, true>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
-                               (u64*)nullptr, p32[in], p32[out], n, shift, c->d_hist);
+                               (u64*)nullptr, p32[in], p32[out], n, shift, q.hist);
         else
             hipLaunchKernelGGL((k_radix_scatter<false, false>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
-                               (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, c->d_hist);
+                               (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist);
         if (timing) { HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used + 1], s)); c->ev_used += 2; }
         c->scatter_bytes += (uint64_t)n * 2 * (8 + (p32 ? 4 : 0) + (p64 ? 8 : 0));
         c->stats.n_radix_passes++;
@@ -774,6 +783,11 @@ int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out) {
         }
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ind, hipEventDisableTiming));
     HIP_TRY(hipMalloc((void**)&c->d_sc, sizeof(Scalars)));
     HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_stop));
     c->ev_scatter.resize(64);
@@ -792,6 +806,8 @@ void mgx_sortdedup_destroy(mgx_sortdedup_t* c) {
     for (auto e : c->ev_scatter) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (int i = 0; i < 2; ++i) { if (c->side[i]) (void)hipStreamDestroy(c->side[i]); if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]); }
+    if (c->ev_ind) (void)hipEventDestroy(c->ev_ind);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
     delete c;
@@ -893,21 +909,44 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     // (sort_key, mate end) identity is ONE injective key word p1 << 18 | orient << 16 | delta, so one
     // LSD sort of (8-byte key, 4-byte record) groups equal pairs: 7 passes x 12 B instead of 9 x 16 B.
     // Runs only need equal keys to be adjacent, not the reference's exact order.
+    // The three sorts are independent: near pairs go to side stream 0, records to side stream 1, far
+    // pairs and singles stay on the main stream, so their short histogram / scan launches overlap the
+    // other sorts' bandwidth-bound scatters.  In-process A/B on one device at 200 M records
+    // (tools/dev_sort_ab.py): 18.0 ms against 19.4 ms on a single stream (MGX_SORTDEDUP_STREAMS=1).
+    const char* env_streams = getenv("MGX_SORTDEDUP_STREAMS");
+    const bool multi = !(env_streams && atoi(env_streams) == 1);
+    hipStream_t sN = (multi && tiled) ? c->side[0] : s;   // the atomic (non-tiled) bitmap needs the memset first
+    hipStream_t sR = multi ? c->side[1] : s;
     int ncur = 0;
-    if ((rc = radix_sort(c, c->d_nk, nullptr, c->d_nrec, nn, 0, bits_of(c->sc.max_near), &ncur))) return rc;
+    if ((rc = radix_sort(c, sN, c->scr[1], c->d_nk, nullptr, c->d_nrec, nn, 0, bits_of(c->sc.max_near), &ncur))) return rc;
     bool defined = false;                     // has a pass already written every word of the tiled bitmap?
     if (tiled && n && c->packed_pair) {
-        hipLaunchKernelGGL(k_indicator_tiles_near, dim3(n_ind_tiles), dim3(256), 0, s, c->d_nk[ncur], nn, c->d_indicator, Lp);
+        hipLaunchKernelGGL(k_indicator_tiles_near, dim3(n_ind_tiles), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, Lp);
         defined = true;
     } else if (!tiled && nn) {
-        hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, s, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
+        hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
     }
+    HIP_TRY(hipEventRecord(c->ev_ind, sN));
     if (nn) {
-        hipLaunchKernelGGL((k_mark_runs<true, false>), dim3((nn + 255) / 256), dim3(256), 0, s, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_n);
-        hipLaunchKernelGGL((k_mark_long<true, false>), dim3(c->n_cu * 2), dim3(256), 0, s, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_n);
+        hipLaunchKernelGGL((k_mark_runs<true, false>), dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[1].longl, &c->d_sc->n_long_n);
+        hipLaunchKernelGGL((k_mark_long<true, false>), dim3(c->n_cu * 2), dim3(256), 0, sN, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[1].longl, &c->d_sc->n_long_n);
     }
+    HIP_TRY(hipEventRecord(c->ev_side[0], sN));
+
+    // records by unified coordinate (stable: equal coordinates keep arrival order)
+    int ccur = 0;
+    if (c->packed_coord) {
+        // key = coord << 32 | arrival index: sort on the high half only, 8 bytes per record per pass
+        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n, 32, bits_of(c->sc.max_coord), &ccur))) return rc;
+        if (n) hipLaunchKernelGGL(k_unpack_order, dim3((n + 255) / 256), dim3(256), 0, sR, c->d_ckey[ccur], n, c->d_cval[0]);
+        ccur = 0;
+    } else {
+        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, c->d_cval, n, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
+    }
+    c->order_buf = ccur;
+    HIP_TRY(hipEventRecord(c->ev_side[1], sR));
 
     // far double pairs (discordant, cross-contig, or every pair when keys are wider than 32 bits):
     // LSD over (sort_key, mate 5' end): sort by the mate end first, then by sort_key.
@@ -916,10 +955,11 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     int cur = 0;
     const bool pk = c->packed_pair;
     if (pk) {
-        if ((rc = radix_sort(c, c->d_k2, c->d_k1, nullptr, nd, 32, bits_of(c->sc.max_k2d), &cur))) return rc;
+        if ((rc = radix_sort(c, s, c->scr[0], c->d_k2, c->d_k1, nullptr, nd, 32, bits_of(c->sc.max_k2d), &cur))) return rc;
     } else {
-        if ((rc = radix_sort(c, c->d_k2, c->d_k1, c->d_prec, nd, 0, bits_of(c->sc.max_k2d), &cur))) return rc;
+        if ((rc = radix_sort(c, s, c->scr[0], c->d_k2, c->d_k1, c->d_prec, nd, 0, bits_of(c->sc.max_k2d), &cur))) return rc;
     }
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_ind, 0));      // the near pass defines the bitmap's words first
     if (tiled && n && (nd || !defined)) {
         const dim3 gt(n_ind_tiles);
         if (defined) {
@@ -934,7 +974,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         if (pk) hipLaunchKernelGGL((k_set_indicator<2, true>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
         else    hipLaunchKernelGGL((k_set_indicator<2, false>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
     }
-    if ((rc = radix_sort(c, c->d_k1, c->d_k2, pk ? nullptr : c->d_prec, nd, 0, bits_of(c->sc.max_k1d), &cur))) return rc;
+    if ((rc = radix_sort(c, s, c->scr[0], c->d_k1, c->d_k2, pk ? nullptr : c->d_prec, nd, 0, bits_of(c->sc.max_k1d), &cur))) return rc;
     if (nd) {
         const dim3 g((nd + 255) / 256), gl(c->n_cu * 2);
         if (tiled) {
@@ -946,36 +986,27 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         }
         if (pk) {
             hipLaunchKernelGGL((k_mark_runs<true, true>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], (const u32*)nullptr, nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
             hipLaunchKernelGGL((k_mark_long<true, true>), gl, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], (const u32*)nullptr, nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
         } else {
             hipLaunchKernelGGL((k_mark_runs<true, false>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
             hipLaunchKernelGGL((k_mark_long<true, false>), gl, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_d);
+                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
         }
     }
     // singles
     int scur = 0;
-    if ((rc = radix_sort(c, c->d_sk1, nullptr, c->d_srec, ns, 0, bits_of(c->sc.max_k1s), &scur))) return rc;
+    if ((rc = radix_sort(c, s, c->scr[0], c->d_sk1, nullptr, c->d_srec, ns, 0, bits_of(c->sc.max_k1s), &scur))) return rc;
     if (ns) {
         hipLaunchKernelGGL((k_mark_runs<false, false>), dim3((ns + 255) / 256), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_s);
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_s);
         hipLaunchKernelGGL((k_mark_long<false, false>), dim3(c->n_cu * 2), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->d_long, &c->d_sc->n_long_s);
+                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_s);
     }
-    // records by unified coordinate (stable: equal coordinates keep arrival order)
-    int ccur = 0;
-    if (c->packed_coord) {
-        // key = coord << 32 | arrival index: sort on the high half only, 8 bytes per record per pass
-        if ((rc = radix_sort(c, c->d_ckey, nullptr, nullptr, n, 32, bits_of(c->sc.max_coord), &ccur))) return rc;
-        if (n) hipLaunchKernelGGL(k_unpack_order, dim3((n + 255) / 256), dim3(256), 0, s, c->d_ckey[ccur], n, c->d_cval[0]);
-        ccur = 0;
-    } else {
-        if ((rc = radix_sort(c, c->d_ckey, nullptr, c->d_cval, n, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
-    }
-    c->order_buf = ccur;
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_side[0], 0));
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_side[1], 0));
     if (n) hipLaunchKernelGGL(k_count_dup, dim3(c->n_cu * 4), dim3(256), 0, s, c->d_dup, n, c->d_sc);
     HIP_TRY(hipEventRecord(c->ev_stop, s));
     HIP_TRY(hipGetLastError());
