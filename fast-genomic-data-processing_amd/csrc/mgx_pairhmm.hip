@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -147,7 +148,9 @@ constexpr uint64_t kMergeBelow = 4096;
 int finalize_bin(Bin& bin, int n_cu) {
     // LDS per group: G pad + codes + G pad + prefetch slack (see the kernel's staging loop)
     bin.lds_stride = (bin.max_h + 2u * (uint32_t)std::max(bin.G, bin.Gd) + 8u + 15u) & ~15u;
-    bin.block = 128;                  // 2 wavefronts: fine-grained LDS/VGPR packing per CU
+    bin.block = 64;                   // one wavefront per workgroup: finest LDS/VGPR packing per CU, no cross-wave
+                                      // barriers; in-process A/B at 1 M pairs: 5.48 ms (64), 5.65 (128), 5.46 (256)
+    if (const char* e = getenv("MGX_PAIRHMM_BLOCK")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) bin.block = (uint32_t)v; }
     while (bin.block > 64u && lds_bytes(bin, true) > kMaxLdsPerBlock) bin.block /= 2;
     if (lds_bytes(bin, true) > 160u * 1024u) {
         set_error("haplotype of %u bases does not fit the LDS staging buffer", bin.max_h);
