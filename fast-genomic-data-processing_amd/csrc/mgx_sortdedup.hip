@@ -651,6 +651,8 @@ struct mgx_sortdedup {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> ev_scatter;    // pairs (start, stop) per scatter launch
     size_t ev_used = 0;
+    size_t ev_rec_begin = 0, ev_rec_end = 0;   // event range of the record sort's scatter launches
+    uint64_t rec_scatter_bytes = 0;
     uint64_t scatter_bytes = 0;
     int order_buf = 0;                     // which d_cval holds the final order
     bool packed_coord = false;             // L < 2^32: coordinate sort on packed (coord, index) words
@@ -937,6 +939,8 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
 
     // records by unified coordinate (stable: equal coordinates keep arrival order)
     int ccur = 0;
+    c->ev_rec_begin = c->ev_used;
+    const uint64_t bytes_before_records = c->scatter_bytes;
     if (c->packed_coord) {
         // key = coord << 32 | arrival index: sort on the high half only, 8 bytes per record per pass
         if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n, 32, bits_of(c->sc.max_coord), &ccur))) return rc;
@@ -946,6 +950,8 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, c->d_cval, n, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
     }
     c->order_buf = ccur;
+    c->ev_rec_end = c->ev_used;
+    c->rec_scatter_bytes = c->scatter_bytes - bytes_before_records;
     HIP_TRY(hipEventRecord(c->ev_side[1], sR));
 
     // far double pairs (discordant, cross-contig, or every pair when keys are wider than 32 bits):
@@ -1042,6 +1048,12 @@ int mgx_sortdedup_stats(mgx_sortdedup_t* c, mgx_sortdedup_stats_t* out) {
         st.ms_radix_scatter += ms;
     }
     st.radix_scatter_bytes = c->scatter_bytes;
+    st.ms_scatter_records = 0; st.n_scatter_records = 0; st.scatter_records_bytes = c->rec_scatter_bytes;
+    for (size_t k = c->ev_rec_begin; k + 1 < c->ev_rec_end + 1 && k < c->ev_rec_end; k += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_scatter[k], c->ev_scatter[k + 1]));
+        st.ms_scatter_records += ms; st.n_scatter_records++;
+    }
     // LSD-8 traffic model, SURVEY.md section 8d
     const uint64_t N = c->n, P = (uint64_t)st.n_double + st.n_single;
     const uint64_t pc = (st.key_bits_coord + 7) / 8, pp = (st.key_bits_pair1 + st.key_bits_pair2 + 7) / 8;

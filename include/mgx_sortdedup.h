@@ -20,7 +20,8 @@
  *                           duplicate_index lookup per record     sortmardup/main.cpp:385-388
  *                           (device code: radix sorts + segmented best-of-run scan)
  *
- * Out of scope of this ABI: SAM text parsing and BGZF/BAI writing.
+ * Not part of this ABI: SAM text parsing and BGZF/BAM/BAI writing -- they live in
+ * the sortmardup-compatible CLI built on top of it (fast-genomic-data-processing_amd/csrc/cli/).
  *
  * All functions return 0 or a negative errno-style code; mgx_last_error() has the message.
  */
@@ -73,6 +74,10 @@ typedef struct mgx_sortdedup_stats {
     float ms_radix_scatter;         /* sum over all radix scatter launches */
     uint64_t radix_scatter_bytes;   /* algorithmic bytes those launches moved (read + write) */
     uint64_t alg_bytes;             /* LSD-8 traffic model of SURVEY.md section 8d for this input */
+    /* the dominant kernel: the scatter launches of the record (coordinate) sort */
+    float ms_scatter_records;       /* sum of their durations */
+    uint32_t n_scatter_records;     /* how many launches */
+    uint64_t scatter_records_bytes; /* algorithmic bytes they moved (read + write) */
 } mgx_sortdedup_stats_t;
 
 /* Host side (B3-B7): pair records by adjacent equal qname exactly as BamParser does, derive the
