@@ -46,6 +46,10 @@ namespace {
 using u64 = unsigned long long;   // == uint64_t on this ABI; the type HIP atomics are declared for
 using u32 = uint32_t;
 
+#ifndef MGX_SCATTER_WAVES
+#define MGX_SCATTER_WAVES 4
+#endif
+constexpr int kScatterWaves = MGX_SCATTER_WAVES;   // wavefronts per scatter workgroup
 constexpr int kTileThreads = 256;
 constexpr int kItems = 16;
 constexpr int kTile = kTileThreads * kItems;          // 4096 keys per workgroup
@@ -268,49 +272,84 @@ __global__ __launch_bounds__(256) void k_radix_apply(u32* __restrict__ hist, u32
     }
 }
 
-template <bool HAS_P64, bool HAS_P32>
-__global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ kin, u64* __restrict__ kout,
-                                                       const u64* __restrict__ pin64, u64* __restrict__ pout64,
-                                                       const u32* __restrict__ pin32, u32* __restrict__ pout32,
-                                                       u32 n, int shift, const u32* __restrict__ goff) {
-    __shared__ u64 sbuf[kTile];             // 32 KB exchange buffer (keys, then payloads)
-    __shared__ u32 wcnt[4][256];
-    __shared__ u32 tile_base[256];
-    __shared__ u32 gbase[256];
-    __shared__ u32 sm[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 tile0 = blockIdx.x * kTile;
-    const u32 tile_n = min((u32)kTile, n - tile0);
+// block-wide exclusive scan over NW wavefronts (every thread of the block must call it)
+template <int NW>
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = v;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
-    gbase[tid] = goff[(size_t)blockIdx.x * 256 + tid];
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) sm[wave] = incl;
+    __syncthreads();
+    u32 base = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const u32 s = sm[w]; if (w < wave) base += s; }
+    return base + incl - v;
+}
+
+// One 4096-key tile per workgroup of WAVES wavefronts; every wavefront ranks a contiguous slice.
+template <bool HAS_P64, bool HAS_P32, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restrict__ kin, u64* __restrict__ kout,
+                                                              const u64* __restrict__ pin64, u64* __restrict__ pout64,
+                                                              const u32* __restrict__ pin32, u32* __restrict__ pout32,
+                                                              u32 n, int shift, const u32* __restrict__ goff, u32 n_tiles, int xcd_order) {
+    constexpr int T = WAVES * 64;           // threads
+    constexpr int ITEMS = kTile / T;        // keys per thread
+    constexpr int SLICE = kTile / WAVES;    // keys per wavefront
+    __shared__ u64 sbuf[kTile];             // 32 KB exchange buffer (keys, then payloads)
+    __shared__ u32 wcnt[WAVES][256];        // per wavefront and digit: running count, later the slot base
+    __shared__ u32 gdelta[256];             // global offset of the digit's run minus its tile-local start
+    __shared__ u32 sm[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2.  A digit's run of
+    // ~16 keys starts at an arbitrary 8-byte offset, so most 128-byte lines are completed by the
+    // NEXT tile: giving each XCD a contiguous range of tiles (walked in order) lets both halves of
+    // such a line meet in one L2 instead of reaching HBM as two partial writes from two L2s.
+    u32 tile = blockIdx.x;
+    if (xcd_order) {
+        const u32 q = n_tiles >> 3, r = n_tiles & 7u, x = blockIdx.x & 7u;
+        tile = x * q + min(x, r) + (blockIdx.x >> 3);
+    }
+    const u32 tile0 = tile * kTile;
+    const u32 tile_n = min((u32)kTile, n - tile0);
+    for (int i = tid; i < WAVES * 256; i += T) (&wcnt[0][0])[i] = 0;
+    const u32 my_goff = tid < 256 ? goff[(size_t)tile * 256 + tid] : 0u;
     __syncthreads();
 
-    // phase 1: stable rank of every key inside its wavefront's 1024-key slice
-    u64 key[kItems];
-    u64 pay[HAS_P64 ? kItems : 1];
-    u32 lrank[kItems];
+    // phase 1: stable rank of every key inside its wavefront's slice
+    u64 key[ITEMS];
+    u64 pay[HAS_P64 ? ITEMS : 1];
+    u32 lrank[ITEMS];
+    constexpr bool KEEP_DIG = !(HAS_P64 && ITEMS > 8);   // register budget: recompute the digit in the widest form
+    u32 dig[KEEP_DIG ? ITEMS : 1];
     const u64 lt = lanemask_lt();
+    const bool hi_word = shift >= 32;       // digits are byte aligned (shift is a multiple of 8): never straddle
+    const int sh = shift & 31;
     // all global loads of the tile are issued up front: the payload's HBM latency is then hidden
-    // behind the ranking arithmetic instead of being exposed between two barriers later on
+    // behind the ranking arithmetic instead of being exposed between two barriers later on.
+    // Slots past the end of the input hold ~0: they are the last of the tile in input order and
+    // carry the last digit, so ranking them like keys changes no valid key's slot.
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const u32 li = wave * (kTile / 4) + k * 64 + lane;      // local index: slices are contiguous per wave
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 li = wave * SLICE + k * 64 + lane;            // local index: slices are contiguous per wave
         key[k] = li < tile_n ? kin[tile0 + li] : ~0ull;
     }
     if constexpr (HAS_P64) {
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const u32 li = wave * (kTile / 4) + k * 64 + lane;
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 li = wave * SLICE + k * 64 + lane;
             pay[k] = li < tile_n ? pin64[tile0 + li] : 0ull;
         }
     }
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const u32 li = wave * (kTile / 4) + k * 64 + lane;
-        const bool valid = li < tile_n;
-        const u32 d = (u32)(key[k] >> shift) & 255u;
-        u64 peers = __ballot(valid);
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 d = ((hi_word ? (u32)(key[k] >> 32) : (u32)key[k]) >> sh) & 255u;
+        if constexpr (KEEP_DIG) dig[k] = d;
+        u64 peers = ~0ull;                                       // lanes holding the same digit
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const bool bit = (d >> b) & 1u;
@@ -319,53 +358,60 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ k
         }
         const u32 r = __popcll(peers & lt);
         u32 old = 0;
-        if (valid && r == 0) old = atomicAdd(&wcnt[wave][d], (u32)__popcll(peers));
-        const int leader = __ffsll((long long)peers) - 1;
-        old = __shfl(old, leader < 0 ? 0 : leader, 64);
+        if (r == 0) old = atomicAdd(&wcnt[wave][d], (u32)__popcll(peers));
+        old = __shfl(old, __ffsll((long long)peers) - 1, 64);
         lrank[k] = old + r;
     }
     __syncthreads();
-    // phase 2: per digit, exclusive over the 4 wavefronts, then exclusive over digits
+    // phase 2: per digit, exclusive over the wavefronts, then exclusive over digits
     {
-        u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-        wcnt[0][tid] = 0; wcnt[1][tid] = c0; wcnt[2][tid] = c0 + c1; wcnt[3][tid] = c0 + c1 + c2;
-        u32 all;
-        tile_base[tid] = block_excl_scan_256(c0 + c1 + c2 + c3, sm, &all);
+        u32 c[WAVES], tot = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { c[w] = wcnt[w][tid]; tot += c[w]; }
+        }
+        const u32 tb = block_excl_scan<WAVES>(tot, sm);          // threads >= 256 contribute 0 after all digits
+        if (tid < 256) {
+            u32 run = tb;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { wcnt[w][tid] = run; run += c[w]; }
+            gdelta[tid] = my_goff - tb;
+        }
     }
     __syncthreads();
     // phase 3: keys to their tile-local sorted slot, then out in runs of consecutive addresses
-    u32 lpos[kItems];
+    u32 lpos[ITEMS];
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const u32 li = wave * (kTile / 4) + k * 64 + lane;
-        const u32 d = (u32)(key[k] >> shift) & 255u;
-        lpos[k] = tile_base[d] + wcnt[wave][d] + lrank[k];
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 li = wave * SLICE + k * 64 + lane;
+        const u32 d = KEEP_DIG ? dig[KEEP_DIG ? k : 0] : ((hi_word ? (u32)(key[k] >> 32) : (u32)key[k]) >> sh) & 255u;
+        lpos[k] = wcnt[wave][d] + lrank[k];
         if (li < tile_n) sbuf[lpos[k]] = key[k];
     }
     __syncthreads();
-    u32 gpos[kItems];
+    u32 gpos[ITEMS];
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const u32 i = k * 256 + tid;
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 i = k * T + tid;
         gpos[k] = 0;
         if (i < tile_n) {
             const u64 kk = sbuf[i];
-            const u32 d = (u32)(kk >> shift) & 255u;
-            gpos[k] = gbase[d] + (i - tile_base[d]);
+            const u32 d = ((hi_word ? (u32)(kk >> 32) : (u32)kk) >> sh) & 255u;
+            gpos[k] = gdelta[d] + i;
             kout[gpos[k]] = kk;
         }
     }
     if constexpr (HAS_P64) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const u32 li = wave * (kTile / 4) + k * 64 + lane;
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 li = wave * SLICE + k * 64 + lane;
             if (li < tile_n) sbuf[lpos[k]] = pay[k];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const u32 i = k * 256 + tid;
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 i = k * T + tid;
             if (i < tile_n) pout64[gpos[k]] = sbuf[i];
         }
     }
@@ -373,14 +419,14 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const u64* __restrict__ k
         __syncthreads();
         u32* sbuf32 = reinterpret_cast<u32*>(sbuf);
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const u32 li = wave * (kTile / 4) + k * 64 + lane;
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 li = wave * SLICE + k * 64 + lane;
             if (li < tile_n) sbuf32[lpos[k]] = pin32[tile0 + li];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const u32 i = k * 256 + tid;
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 i = k * T + tid;
             if (i < tile_n) pout32[gpos[k]] = sbuf32[i];
         }
     }
@@ -658,6 +704,7 @@ struct mgx_sortdedup {
     bool packed_coord = false;             // L < 2^32: coordinate sort on packed (coord, index) words
     bool packed_pair = false;              // every 5' end < 2^32: (mate end, record) ride in one word
     bool ran = false;
+    int xcd_order = 1;                     // scatter tiles walk each XCD's contiguous range (MGX_SORTDEDUP_XCD_ORDER=0: plain)
     Scalars sc{};
     mgx_sortdedup_stats_t stats{};
 };
@@ -726,17 +773,17 @@ int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q,
         const bool timing = c->ev_used + 2 <= c->ev_scatter.size();
         if (timing) HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used], s));
         if (p64 && !p32)
-            hipLaunchKernelGGL((k_radix_scatter<true, false>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
-                               (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist);
+            hipLaunchKernelGGL((k_radix_scatter<true, false, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], p64[in], p64[out],
+                               (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist, n_tiles, c->xcd_order);
         else if (p64)
-            hipLaunchKernelGGL((k_radix_scatter<true, true>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], p64[in], p64[out],
-                               p32[in], p32[out], n, shift, q.hist);
+            hipLaunchKernelGGL((k_radix_scatter<true, true, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], p64[in], p64[out],
+                               p32[in], p32[out], n, shift, q.hist, n_tiles, c->xcd_order);
         else if (p32)
-            hipLaunchKernelGGL((k_radix_scatter<false, true>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
-                               (u64*)nullptr, p32[in], p32[out], n, shift, q.hist);
+            hipLaunchKernelGGL((k_radix_scatter<false, true, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
+                               (u64*)nullptr, p32[in], p32[out], n, shift, q.hist, n_tiles, c->xcd_order);
         else
-            hipLaunchKernelGGL((k_radix_scatter<false, false>), dim3(n_tiles), dim3(256), 0, s, key[in], key[out], (const u64*)nullptr,
-                               (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist);
+            hipLaunchKernelGGL((k_radix_scatter<false, false, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
+                               (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist, n_tiles, c->xcd_order);
         if (timing) { HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used + 1], s)); c->ev_used += 2; }
         c->scatter_bytes += (uint64_t)n * 2 * (8 + (p32 ? 4 : 0) + (p64 ? 8 : 0));
         c->stats.n_radix_passes++;
@@ -915,6 +962,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     // pairs and singles stay on the main stream, so their short histogram / scan launches overlap the
     // other sorts' bandwidth-bound scatters.  In-process A/B on one device at 200 M records
     // (tools/dev_sort_ab.py): 18.0 ms against 19.4 ms on a single stream (MGX_SORTDEDUP_STREAMS=1).
+    if (const char* e = getenv("MGX_SORTDEDUP_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
     const char* env_streams = getenv("MGX_SORTDEDUP_STREAMS");
     const bool multi = !(env_streams && atoi(env_streams) == 1);
     hipStream_t sN = (multi && tiled) ? c->side[0] : s;   // the atomic (non-tiled) bitmap needs the memset first
