@@ -247,17 +247,31 @@ __global__ __launch_bounds__(256) void k_radix_chunk_sums(const u32* __restrict_
     chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-// one block: digit bases (exclusive over digits) + exclusive scan over chunks per digit column
+// one block: digit bases (exclusive over digits) + exclusive scan over chunks per digit column.
+// A single workgroup alone on the device is pure latency, so both loops keep 16 independent loads in
+// flight per thread (the in-place update would otherwise serialise on load -> store -> load).
 __global__ __launch_bounds__(256) void k_radix_scan_chunks(u32* chunk_sums, u32 n_chunks) {
     __shared__ u32 sm[4];
+    constexpr int B = 16;
     u32 tot = 0;
-    for (u32 c = 0; c < n_chunks; ++c) tot += chunk_sums[(size_t)c * 256 + threadIdx.x];
+    for (u32 c0 = 0; c0 < n_chunks; c0 += B) {
+        u32 x[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) x[k] = c0 + k < n_chunks ? chunk_sums[(size_t)(c0 + k) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int k = 0; k < B; ++k) tot += x[k];
+    }
     u32 all;
     u32 run = block_excl_scan_256(tot, sm, &all);      // where this digit starts in the output
-    for (u32 c = 0; c < n_chunks; ++c) {
-        const u32 x = chunk_sums[(size_t)c * 256 + threadIdx.x];
-        chunk_sums[(size_t)c * 256 + threadIdx.x] = run;
-        run += x;
+    for (u32 c0 = 0; c0 < n_chunks; c0 += B) {
+        u32 x[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) x[k] = c0 + k < n_chunks ? chunk_sums[(size_t)(c0 + k) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            if (c0 + k < n_chunks) chunk_sums[(size_t)(c0 + k) * 256 + threadIdx.x] = run;
+            run += x[k];
+        }
     }
 }
 
@@ -265,10 +279,16 @@ __global__ __launch_bounds__(256) void k_radix_scan_chunks(u32* chunk_sums, u32 
 __global__ __launch_bounds__(256) void k_radix_apply(u32* __restrict__ hist, u32 n_tiles, const u32* __restrict__ chunk_sums) {
     const u32 t0 = blockIdx.x * kChunkTiles, t1 = min(n_tiles, t0 + kChunkTiles);
     u32 run = chunk_sums[(size_t)blockIdx.x * 256 + threadIdx.x];
-    for (u32 t = t0; t < t1; ++t) {
-        const u32 x = hist[(size_t)t * 256 + threadIdx.x];
-        hist[(size_t)t * 256 + threadIdx.x] = run;
-        run += x;
+    constexpr int B = 16;
+    for (u32 tb = t0; tb < t1; tb += B) {
+        u32 x[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) x[k] = tb + k < t1 ? hist[(size_t)(tb + k) * 256 + threadIdx.x] : 0u;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            if (tb + k < t1) hist[(size_t)(tb + k) * 256 + threadIdx.x] = run;
+            run += x[k];
+        }
     }
 }
 
@@ -292,7 +312,9 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sm) {
 }
 
 // One 4096-key tile per workgroup of WAVES wavefronts; every wavefront ranks a contiguous slice.
-template <bool HAS_P64, bool HAS_P32, int WAVES>
+// LOW32: last pass of the packed record sort -- only the low half of every key (the arrival index)
+// is stored, to pout32, which makes the sorted keys themselves unnecessary.
+template <bool HAS_P64, bool HAS_P32, int WAVES, bool LOW32 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                               const u64* __restrict__ pin64, u64* __restrict__ pout64,
                                                               const u32* __restrict__ pin32, u32* __restrict__ pout32,
@@ -398,7 +420,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restr
             const u64 kk = sbuf[i];
             const u32 d = ((hi_word ? (u32)(kk >> 32) : (u32)kk) >> sh) & 255u;
             gpos[k] = gdelta[d] + i;
-            kout[gpos[k]] = kk;
+            if constexpr (LOW32) pout32[gpos[k]] = (u32)kk;
+            else kout[gpos[k]] = kk;
         }
     }
     if constexpr (HAS_P64) {
@@ -760,7 +783,8 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
 // one stable LSD radix sort of (key, [p64], p32) over `bits` low bits of the key
 // buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
 int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q, u64* key[2], u64* p64[2], u32* p32[2], u32 n,
-               int first_shift, int bits, int* cur) {
+               int first_shift, int bits, int* cur, u32* low32_out = nullptr, bool* low32_done = nullptr) {
+    if (low32_done) *low32_done = false;
     if (n == 0) return 0;
     const u32 n_tiles = (n + kTile - 1) / kTile;
     const u32 n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
@@ -781,11 +805,16 @@ int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q,
         else if (p32)
             hipLaunchKernelGGL((k_radix_scatter<false, true, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
                                (u64*)nullptr, p32[in], p32[out], n, shift, q.hist, n_tiles, c->xcd_order);
-        else
+        else if (low32_out && shift + 8 >= first_shift + bits) {
+            hipLaunchKernelGGL((k_radix_scatter<false, false, kScatterWaves, true>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
+                               (u64*)nullptr, (const u32*)nullptr, low32_out, n, shift, q.hist, n_tiles, c->xcd_order);
+            if (low32_done) *low32_done = true;
+        } else
             hipLaunchKernelGGL((k_radix_scatter<false, false, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
                                (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist, n_tiles, c->xcd_order);
         if (timing) { HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used + 1], s)); c->ev_used += 2; }
         c->scatter_bytes += (uint64_t)n * 2 * (8 + (p32 ? 4 : 0) + (p64 ? 8 : 0));
+        if (low32_done && *low32_done) c->scatter_bytes -= (uint64_t)n * 4;
         c->stats.n_radix_passes++;
         *cur = out;
     }
@@ -987,12 +1016,13 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
 
     // records by unified coordinate (stable: equal coordinates keep arrival order)
     int ccur = 0;
+    bool unpacked = false;                    // did the last pass store the order directly?
     c->ev_rec_begin = c->ev_used;
     const uint64_t bytes_before_records = c->scatter_bytes;
     if (c->packed_coord) {
         // key = coord << 32 | arrival index: sort on the high half only, 8 bytes per record per pass
-        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n, 32, bits_of(c->sc.max_coord), &ccur))) return rc;
-        if (n) hipLaunchKernelGGL(k_unpack_order, dim3((n + 255) / 256), dim3(256), 0, sR, c->d_ckey[ccur], n, c->d_cval[0]);
+        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n, 32, bits_of(c->sc.max_coord), &ccur, c->d_cval[0], &unpacked))) return rc;
+        if (n && !unpacked) hipLaunchKernelGGL(k_unpack_order, dim3((n + 255) / 256), dim3(256), 0, sR, c->d_ckey[ccur], n, c->d_cval[0]);
         ccur = 0;
     } else {
         if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, c->d_cval, n, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
@@ -1000,6 +1030,12 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     c->order_buf = ccur;
     c->ev_rec_end = c->ev_used;
     c->rec_scatter_bytes = c->scatter_bytes - bytes_before_records;
+    if (unpacked && c->ev_rec_end >= c->ev_rec_begin + 2) {
+        // the statistics of "the record-sort scatter kernel" cover the full-width launches only; the
+        // last one is a different instantiation (half the store bytes)
+        c->ev_rec_end -= 2;
+        c->rec_scatter_bytes -= (uint64_t)n * 12;
+    }
     HIP_TRY(hipEventRecord(c->ev_side[1], sR));
 
     // far double pairs (discordant, cross-contig, or every pair when keys are wider than 32 bits):
