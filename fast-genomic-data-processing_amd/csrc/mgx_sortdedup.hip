@@ -57,11 +57,17 @@ constexpr int kChunkTiles = 128;                      // tiles per column-scan c
 constexpr u32 kIgnorable = 0x4 | 0x100 | 0x800;
 constexpr int kWalkCap = 64;                          // longest run a single lane walks
 
-struct Scalars {            // device-side scalars, one 64-byte read-back
+// Device-side scalars, one small read-back.  Every workgroup of the build kernel bumps the entry
+// counters, so each one sits in its own 128-byte line (atomics on one line serialise at ~90/us and
+// would otherwise also stall the plain reads of the maxima next to them).
+struct Scalars {
     u64 max_coord, max_k1d, max_k2d, max_k1s, max_near;
-    u32 n_double, n_single, n_long_d, n_long_s;    // n_double: "far" double pairs (two-word keys)
-    u32 n_dup, bad_mate, n_near, n_long_n;         // bad_mate: a record names a mate index outside the shard
-    u32 pad_[2];
+    u32 n_long_d, n_long_s, n_long_n, n_dup;
+    u32 bad_mate;                              // a record names a mate index outside the shard
+    u32 pad0_[17];
+    alignas(128) u32 n_double; u32 pad1_[31];  // "far" double pairs (two-word keys)
+    alignas(128) u32 n_single; u32 pad2_[31];
+    alignas(128) u32 n_near;   u32 pad3_[31];
 };
 constexpr u64 kNearSpan = 65536;       // near pair: mate 5' end less than this beyond record 1's
 
@@ -90,7 +96,7 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* sm, u32* total) {
 // ---------------------------------------------------------------------------------------------
 // build: classify records, count entries per 1024-record block
 // ---------------------------------------------------------------------------------------------
-constexpr int kBuildBlock = 8192;
+constexpr int kBuildBlock = 2048;
 
 __device__ __forceinline__ int classify(const mgx_rec_t& r, u32 i) {
     // 0 = no entry, 1 = record 1 of a double pair, 2 = single pair
@@ -111,69 +117,83 @@ struct BuildOut {
     int near_enabled;
 };
 
-// Entries are compacted with one global atomic per wavefront and kind, so their order is not the
+// Entries are compacted with one global atomic per workgroup and kind, so their order is not the
 // arrival order; nothing downstream depends on it: runs are formed by key equality and total ties
 // between entries are broken by the record index itself (k_mark_runs), not by position.
-__global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n, BuildOut o, Scalars* sc) {
+//
+// Single pass over the records: a workgroup reads its 2048 records once (all loads issued up
+// front), classifies them, keeps the derived entry words in registers while the per-kind counts
+// are settled (LDS atomics give block-local slots, ONE global atomic per kind gives the block's
+// base -- a single counter word sustains only ~90 atomics/us, never one per wavefront), then
+// stores the entries.  The mate's record is read through the cache: mates are adjacent in arrival
+// order, so the line is already there.
+__global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict__ recs, u32 n, BuildOut o, Scalars* sc) {
+    constexpr int ITEMS = kBuildBlock / 256;
     __shared__ u64 smax[4][5];
     __shared__ u32 s_cnt[3], s_base[3];
     const u32 base = blockIdx.x * kBuildBlock;
     const u64 lt = lanemask_lt();
-    // pass A: how many entries of each kind does this block produce -> ONE global atomic per kind
-    // (a single counter word sustains only ~90 atomics/us: never one per wavefront)
     if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    {
-        u32 cd = 0, cs = 0, cn = 0;
-        for (int k = 0; k < kBuildBlock / 256; ++k) {
-            const u32 i = base + k * 256 + threadIdx.x;
-            if (i < n) {
-                // classify() needs flag and mate only: bytes 16..21 of the 32-byte record
-                const u32 mate = recs[i].mate; const u32 flag = recs[i].flag;
-                int c = ((flag & kIgnorable) || (mate != MGX_NO_MATE && mate >= n)) ? 0 : (mate == MGX_NO_MATE ? 2 : (mate > i ? 1 : 0));
-                if (c == 1 && o.near_enabled) {
-                    const u64 a5 = recs[i].prime5, b5 = recs[mate].prime5;
-                    if ((a5 > b5 ? a5 - b5 : b5 - a5) < kNearSpan) c = 3;
-                }
-                cd += c == 1; cs += c == 2; cn += c == 3;
-            }
-        }
+
+    u64 coord[ITEMS], p5[ITEMS];
+    u32 mate[ITEMS], flag[ITEMS];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { cd += __shfl_xor(cd, off, 64); cs += __shfl_xor(cs, off, 64); cn += __shfl_xor(cn, off, 64); }
-        if ((threadIdx.x & 63) == 0) { if (cd) atomicAdd(&s_cnt[0], cd); if (cs) atomicAdd(&s_cnt[1], cs); if (cn) atomicAdd(&s_cnt[2], cn); }
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        coord[k] = 0; p5[k] = 0; mate[k] = MGX_NO_MATE; flag[k] = kIgnorable;
+        if (i < n) { coord[k] = recs[i].coord; p5[k] = recs[i].prime5; mate[k] = recs[i].mate; flag[k] = recs[i].flag; }
     }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const u32 cnt = s_cnt[threadIdx.x];
-        u32* dst = threadIdx.x == 0 ? &sc->n_double : threadIdx.x == 1 ? &sc->n_single : &sc->n_near;
-        s_base[threadIdx.x] = cnt ? atomicAdd(dst, cnt) : 0u;
-        s_cnt[threadIdx.x] = 0;                 // reused below as the block-local running offset
+    u64 mp5[ITEMS]; u32 mflag[ITEMS];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        if (i < n && mate[k] != MGX_NO_MATE && mate[k] >= n) { bad = true; mate[k] = MGX_NO_MATE; flag[k] |= kIgnorable; }
+        mp5[k] = 0; mflag[k] = 0;
+        // only record 1 of a pair (mate > i, not ignorable) looks at its mate
+        if (i < n && !(flag[k] & kIgnorable) && mate[k] != MGX_NO_MATE && mate[k] > i) { mp5[k] = recs[mate[k]].prime5; mflag[k] = recs[mate[k]].flag; }
     }
-    __syncthreads();
+    if (bad) sc->bad_mate = 1;
+
+    u64 ka[ITEMS], kb[ITEMS];       // entry words: near key | sort_key ; mate end (far doubles only)
+    u32 slot[ITEMS];                // block-local slot within the entry's kind
+    int cls[ITEMS];                 // 0 none, 1 far double, 2 single, 3 near double
     u64 m_coord = 0, m_k1d = 0, m_k2d = 0, m_k1s = 0, m_near = 0;
-    for (int k = 0; k < kBuildBlock / 256; ++k) {
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
         const u32 i = base + k * 256 + threadIdx.x;
         int c = 0;
-        mgx_rec_t r;
-        u64 p1 = 0, p2 = 0; u32 orient = 0;
+        u64 wa = 0, wb = 0;
         if (i < n) {
-            r = recs[i];
-            if (r.mate != MGX_NO_MATE && r.mate >= n) { sc->bad_mate = 1; r.mate = MGX_NO_MATE; r.flag |= (uint16_t)kIgnorable; }
-            c = classify(r, i);
-            o.ckey[i] = o.packed_coord ? ((u64)r.coord << 32) | i : (u64)r.coord;
+            o.ckey[i] = o.packed_coord ? (coord[k] << 32) | i : coord[k];
             if (!o.packed_coord) o.cval[i] = i;
-            m_coord = max(m_coord, (u64)r.coord);
+            m_coord = max(m_coord, coord[k]);
+            if (!(flag[k] & kIgnorable)) c = mate[k] == MGX_NO_MATE ? 2 : (mate[k] > i ? 1 : 0);
             if (c == 1) {
                 // DoublePair::DoublePair, pair.cpp:71-108
-                const mgx_rec_t m = recs[r.mate];
-                p1 = r.prime5; p2 = m.prime5;
-                bool f1 = !(r.flag & 0x10), f2 = !(m.flag & 0x10);
+                u64 p1 = p5[k], p2 = mp5[k];
+                bool f1 = !(flag[k] & 0x10), f2 = !(mflag[k] & 0x10);
                 if (p1 > p2) { const u64 t = p1; p1 = p2; p2 = t; const bool tf = f1; f1 = f2; f2 = tf; }
-                orient = f1 ? (f2 ? 0u : 1u) : (f2 ? 2u : 3u);       // FF FR RF RR
+                u32 orient = f1 ? (f2 ? 0u : 1u) : (f2 ? 2u : 3u);       // FF FR RF RR
                 if (p1 == p2 && orient == 2u) orient = 1u;
-                if (o.near_enabled && p2 - p1 < kNearSpan) c = 3;
+                const u64 k1 = (p1 << 2) + orient;
+                m_k1d = max(m_k1d, k1); m_k2d = max(m_k2d, p2);
+                // near pair: the whole (sort_key, mate end) identity fits one word, injectively
+                const bool near = o.near_enabled && p2 - p1 < kNearSpan;
+                const u64 nkey = (p1 << 18) | ((u64)orient << 16) | (p2 - p1);
+                c = near ? 3 : 1;
+                wa = near ? nkey : k1;
+                wb = p2;
+                if (near) m_near = max(m_near, nkey);
+            } else if (c == 2) {
+                // SinglePair::SinglePair, pair.cpp:51-69
+                wa = (p5[k] << 2) + ((flag[k] & 0x10) ? 3u : 0u);
+                m_k1s = max(m_k1s, wa);
             }
         }
+        ka[k] = wa; kb[k] = wb;
+        cls[k] = c;
         const u64 bd = __ballot(c == 1), bs = __ballot(c == 2), bn = __ballot(c == 3);
         u32 based = 0, bases = 0, basen = 0;
         if ((threadIdx.x & 63) == 0) {
@@ -181,28 +201,32 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
             if (bs) bases = atomicAdd(&s_cnt[1], (u32)__popcll(bs));
             if (bn) basen = atomicAdd(&s_cnt[2], (u32)__popcll(bn));
         }
-        based = __shfl(based, 0, 64) + s_base[0]; bases = __shfl(bases, 0, 64) + s_base[1]; basen = __shfl(basen, 0, 64) + s_base[2];
-        if (c == 1 || c == 3) { m_k1d = max(m_k1d, (p1 << 2) + orient); m_k2d = max(m_k2d, p2); }
-        if (c == 3) {
-            // near pair: the whole (sort_key, mate end) identity fits one word, injectively
-            const u64 key = (p1 << 18) | ((u64)orient << 16) | (p2 - p1);
-            const u32 at = basen + (u32)__popcll(bn & lt);
-            o.nk[at] = key; o.nrec[at] = i;
-            m_near = max(m_near, key);
-        } else if (c == 1) {
-            const u64 k1 = (p1 << 2) + orient;
-            const u32 at = based + (u32)__popcll(bd & lt);
-            o.dk1[at] = k1;
-            if (o.packed_pair) o.dk2[at] = (p2 << 32) | i; else { o.dk2[at] = p2; o.drec[at] = i; }
-        } else if (c == 2) {
-            // SinglePair::SinglePair, pair.cpp:51-69
-            const u64 k1 = (r.prime5 << 2) + ((r.flag & 0x10) ? 3u : 0u);
-            const u32 at = bases + (u32)__popcll(bs & lt);
-            o.sk1[at] = k1; o.srec[at] = i;
-            m_k1s = max(m_k1s, k1);
+        based = __shfl(based, 0, 64); bases = __shfl(bases, 0, 64); basen = __shfl(basen, 0, 64);
+        slot[k] = c == 1 ? based + (u32)__popcll(bd & lt) : c == 2 ? bases + (u32)__popcll(bs & lt) : basen + (u32)__popcll(bn & lt);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const u32 cnt = s_cnt[threadIdx.x];
+        u32* dst = threadIdx.x == 0 ? &sc->n_double : threadIdx.x == 1 ? &sc->n_single : &sc->n_near;
+        s_base[threadIdx.x] = cnt ? atomicAdd(dst, cnt) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        if (cls[k] == 3) {
+            const u32 at = s_base[2] + slot[k];
+            o.nk[at] = ka[k]; o.nrec[at] = i;
+        } else if (cls[k] == 1) {
+            const u32 at = s_base[0] + slot[k];
+            o.dk1[at] = ka[k];
+            if (o.packed_pair) o.dk2[at] = (kb[k] << 32) | i; else { o.dk2[at] = kb[k]; o.drec[at] = i; }
+        } else if (cls[k] == 2) {
+            const u32 at = s_base[1] + slot[k];
+            o.sk1[at] = ka[k]; o.srec[at] = i;
         }
     }
-    // block max -> 4 global atomics
+    // block max -> global atomics, skipped when the (possibly stale) global value already covers it
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* recs, u32 n
         const u64 v = max(max(smax[0][threadIdx.x], smax[1][threadIdx.x]), max(smax[2][threadIdx.x], smax[3][threadIdx.x]));
         u64* dst = threadIdx.x == 0 ? &sc->max_coord : threadIdx.x == 1 ? &sc->max_k1d : threadIdx.x == 2 ? &sc->max_k2d
                  : threadIdx.x == 3 ? &sc->max_k1s : &sc->max_near;
-        if (v) atomicMax(dst, v);
+        if (v > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, v);
     }
 }
 

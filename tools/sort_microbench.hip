@@ -21,9 +21,11 @@ __global__ __launch_bounds__(256) void k_copy(const u64* __restrict__ in, u64* _
     for (int k = 0; k < 16; ++k) { const u32 i = base + k * 256 + threadIdx.x; if (i < n) out[i] = v[k]; }
 }
 
-template <int RUN>   // RUN keys per run (16 = 128 B, 32 = 256 B, 8 = 64 B)
+template <int RUN, bool XCD>   // RUN keys per run (16 = 128 B, 2 = 16 B ...); XCD: each XCD walks a contiguous tile range
 __global__ __launch_bounds__(256) void k_segscatter(const u64* __restrict__ in, u64* __restrict__ out, u32 n, u32 n_tiles) {
-    const u32 t = blockIdx.x, base = t * 4096;
+    u32 t = blockIdx.x;
+    if (XCD) { const u32 q = n_tiles >> 3, r = n_tiles & 7u, x = blockIdx.x & 7u; t = x * q + min(x, r) + (blockIdx.x >> 3); }
+    const u32 base = t * 4096;
     constexpr int kRuns = 4096 / RUN;                 // runs per tile = number of buckets
     const u32 bucket_len = n / kRuns;                 // n is a multiple of 4096
     u64 v[16];
@@ -36,7 +38,6 @@ __global__ __launch_bounds__(256) void k_segscatter(const u64* __restrict__ in, 
         out[(size_t)d * bucket_len + (size_t)t * RUN + j] = v[k];
     }
 }
-
 
 // ---- staged replica of the scatter pass: STAGE 0 = load + LDS exchange with a fixed permutation + store,
 // 1 = + digit match / rank arithmetic (result discarded into the permutation), 2 = + LDS counter atomics
@@ -148,10 +149,14 @@ int main(int argc, char** argv) {
     float ms;
 #define TIME(name, launch, bytes) do { for (int w = 0; w < 2; ++w) { launch; } CK(hipEventRecord(e0)); for (int r = 0; r < 5; ++r) { launch; } CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); report(name, ms / 5, bytes); } while (0)
     TIME("copy u64", (k_copy<<<tiles, 256>>>(a, b, n)), (double)n * 16);
-    TIME("segscatter 64 B runs", (k_segscatter<8><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
-    TIME("segscatter 128 B runs", (k_segscatter<16><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
-    TIME("segscatter 256 B runs", (k_segscatter<32><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
-    TIME("segscatter 512 B runs", (k_segscatter<64><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter  16 B runs", (k_segscatter<2, false><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter  16 B runs xcd", (k_segscatter<2, true><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter  32 B runs", (k_segscatter<4, false><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter  32 B runs xcd", (k_segscatter<4, true><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter  64 B runs", (k_segscatter<8, false><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter  64 B runs xcd", (k_segscatter<8, true><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter 128 B runs", (k_segscatter<16, false><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
+    TIME("segscatter 128 B runs xcd", (k_segscatter<16, true><<<tiles, 256>>>(a, b, n, tiles)), (double)n * 16);
     {   // random keys for the staged replica
         u64* h = (u64*)malloc((size_t)n * 8);
         u64 x = 88172645463325252ull;
