@@ -68,6 +68,7 @@ struct Scalars {
     alignas(128) u32 n_double; u32 pad1_[31];  // "far" double pairs (two-word keys)
     alignas(128) u32 n_single; u32 pad2_[31];
     alignas(128) u32 n_near;   u32 pad3_[31];
+    alignas(128) u32 n_multi_d; u32 n_multi_s, n_multi_n; u32 pad4_[29];   // run heads with more than one entry
 };
 constexpr u64 kNearSpan = 65536;       // near pair: mate 5' end less than this beyond record 1's
 
@@ -119,7 +120,7 @@ struct BuildOut {
 
 // Entries are compacted with one global atomic per workgroup and kind, so their order is not the
 // arrival order; nothing downstream depends on it: runs are formed by key equality and total ties
-// between entries are broken by the record index itself (k_mark_runs), not by position.
+// between entries are broken by the record index itself (k_mark_list), not by position.
 //
 // Single pass over the records: a workgroup reads its 2048 records once (all loads issued up
 // front), classifies them, keeps the derived entry words in registers while the per-kind counts
@@ -605,46 +606,97 @@ __device__ __forceinline__ u64 quality_single(const mgx_rec_t* recs, u32 rec) {
     return ((u64)(0xFFFFu - (u32)a.score) << 48) | ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y;
 }
 
-// One lane per run head walks its run (runs are short); runs longer than kWalkCap go to a list
-// that k_mark_long handles with a whole workgroup each.
-// PK: the second array holds (mate 5' end << 32 | record) packed in one word and `rec` is unused
+// Duplicate search over the sorted entries, in two steps so that the random-access part runs dense:
+//   k_find_runs : one lane per entry finds the run heads.  A run of ONE entry (nine in ten) needs no
+//                 quality comparison at all: nothing to mark for pairs; for singles only the
+//                 indicator test of main.cpp:325-331.  Heads of longer runs are appended to a list
+//                 (LDS slots + one global atomic per 4096-entry workgroup; list order is irrelevant).
+//   k_mark_list : one lane per listed head walks its run (runs are short), gathers the records'
+//                 quality words and marks everything but the best.  Runs longer than kWalkCap go to
+//                 a second list that k_mark_long handles with a whole workgroup each.
+// PK: the second array holds (mate 5' end << 32 | record) packed in one word and `rec` is unused.
+constexpr int kFindItems = 16;
+
 template <bool DOUBLE, bool PK>
-__global__ __launch_bounds__(256) void k_mark_runs(const u64* __restrict__ k1, const u64* __restrict__ k2,
-                                                   const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
+__global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, const u64* __restrict__ k2,
+                                                   const u32* __restrict__ rec, u32 n,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
-                                                   uint8_t* __restrict__ dup, u32* __restrict__ long_list, u32* n_long) {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+                                                   uint8_t* __restrict__ dup, u32* __restrict__ multi_list, u32* n_multi) {
+    __shared__ u32 s_cnt, s_base;
     // near pairs come as DOUBLE with k2 == nullptr: the single key word is the whole identity
     auto K2 = [&](u32 t) -> u64 { return (!DOUBLE || !k2) ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
     auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
-    const u64 a1 = k1[i], a2 = K2(i);
-    if (i > 0 && k1[i - 1] == a1 && (!DOUBLE || K2(i - 1) == a2)) return;      // not a run head
-    // a run of one entry (nine runs in ten) needs no quality at all: the records are only gathered
-    // once a second entry with the same key shows up
-    u32 best = i;
-    u64 bq = 0;
-    u32 j = i + 1;
-    for (; j < n && j - i < kWalkCap; ++j) {
-        if (k1[j] != a1 || (DOUBLE && K2(j) != a2)) break;
-        if (j == i + 1) bq = DOUBLE ? quality_double(recs, REC(i)) : quality_single(recs, REC(i));
-        const u64 q = DOUBLE ? quality_double(recs, REC(j)) : quality_single(recs, REC(j));
-        if (q < bq || (q == bq && REC(j) < REC(best))) { bq = q; best = j; }
+    const u32 base = blockIdx.x * (256 * kFindItems);
+    const u64 lt = lanemask_lt();
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    u32 slot[kFindItems];
+    u32 is_multi = 0;
+#pragma unroll
+    for (int k = 0; k < kFindItems; ++k) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        bool multi = false;
+        if (i < n) {
+            const u64 a1 = k1[i], a2 = K2(i);
+            const bool head = i == 0 || k1[i - 1] != a1 || (DOUBLE && K2(i - 1) != a2);
+            if (head) {
+                multi = i + 1 < n && k1[i + 1] == a1 && (!DOUBLE || K2(i + 1) == a2);
+                if (!DOUBLE && !multi) {
+                    // main.cpp:325-331: the kept single is a duplicate iff a double pair has an end there
+                    const u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
+                    if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[REC(i)] = 1;
+                }
+            }
+        }
+        const u64 bm = __ballot(multi);
+        u32 wbase = 0;
+        if ((threadIdx.x & 63) == 0 && bm) wbase = atomicAdd(&s_cnt, (u32)__popcll(bm));
+        wbase = __shfl(wbase, 0, 64);
+        slot[k] = wbase + (u32)__popcll(bm & lt);
+        is_multi |= (multi ? 1u : 0u) << k;
     }
-    if (j < n && j - i >= kWalkCap && k1[j] == a1 && (!DOUBLE || K2(j) == a2)) {
-        long_list[atomicAdd(n_long, 1u)] = i;                                     // long run: defer
-        return;
-    }
-    if (!DOUBLE) {
-        // main.cpp:325-331: the kept single is a duplicate iff a double pair has an end there
-        u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
-        if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[REC(best)] = 1;
-    }
-    for (u32 t = i; t < j; ++t) {
-        if (t == best) continue;
-        const u32 r = REC(t);
-        dup[r] = 1;
-        if (DOUBLE) dup[recs[r].mate] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(n_multi, s_cnt) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kFindItems; ++k)
+        if ((is_multi >> k) & 1u) multi_list[s_base + slot[k]] = base + k * 256 + threadIdx.x;
+}
+
+template <bool DOUBLE, bool PK>
+__global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, const u64* __restrict__ k2,
+                                                   const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
+                                                   const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
+                                                   uint8_t* __restrict__ dup, const u32* __restrict__ multi_list, const u32* n_multi,
+                                                   u32* __restrict__ long_list, u32* n_long) {
+    auto K2 = [&](u32 t) -> u64 { return (!DOUBLE || !k2) ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
+    auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
+    const u32 total = *n_multi;
+    for (u32 li = blockIdx.x * 256 + threadIdx.x; li < total; li += gridDim.x * 256) {
+        const u32 i = multi_list[li];
+        const u64 a1 = k1[i], a2 = K2(i);
+        u32 best = i;
+        u64 bq = DOUBLE ? quality_double(recs, REC(i)) : quality_single(recs, REC(i));
+        u32 j = i + 1;
+        for (; j < n && j - i < kWalkCap; ++j) {
+            if (k1[j] != a1 || (DOUBLE && K2(j) != a2)) break;
+            const u64 q = DOUBLE ? quality_double(recs, REC(j)) : quality_single(recs, REC(j));
+            if (q < bq || (q == bq && REC(j) < REC(best))) { bq = q; best = j; }
+        }
+        if (j < n && j - i >= kWalkCap && k1[j] == a1 && (!DOUBLE || K2(j) == a2)) {
+            long_list[atomicAdd(n_long, 1u)] = i;                                     // long run: defer
+            continue;
+        }
+        if (!DOUBLE) {
+            const u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
+            if (target < indicator_bits && ((indicator[target >> 5] >> (target & 31)) & 1u)) dup[REC(best)] = 1;
+        }
+        for (u32 t = i; t < j; ++t) {
+            if (t == best) continue;
+            const u32 r = REC(t);
+            dup[r] = 1;
+            if (DOUBLE) dup[recs[r].mate] = 1;
+        }
     }
 }
 
@@ -732,7 +784,7 @@ struct mgx_sortdedup {
     u64* d_nk[2] = {nullptr, nullptr}; u32* d_nrec[2] = {nullptr, nullptr};     // near double pairs
     // three independent sorts run concurrently (main: far pairs + singles, side[0]: near pairs,
     // side[1]: records), each with its own histogram / scan / long-run scratch
-    struct Scratch { u32 *hist = nullptr, *chunk = nullptr, *longl = nullptr; } scr[3];
+    struct Scratch { u32 *hist = nullptr, *chunk = nullptr, *longl = nullptr, *multi = nullptr; } scr[3];
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_ind = nullptr, ev_side[2] = {nullptr, nullptr};
     u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
@@ -769,7 +821,7 @@ void free_buffers(mgx_sortdedup* c) {
         c->d_ckey[i] = c->d_k1[i] = c->d_k2[i] = c->d_sk1[i] = nullptr;
         c->d_cval[i] = c->d_prec[i] = c->d_srec[i] = nullptr;
     }
-    for (auto& q : c->scr) { (void)hipFree(q.hist); (void)hipFree(q.chunk); (void)hipFree(q.longl); q.hist = q.chunk = q.longl = nullptr; }
+    for (auto& q : c->scr) { (void)hipFree(q.hist); (void)hipFree(q.chunk); (void)hipFree(q.longl); (void)hipFree(q.multi); q.hist = q.chunk = q.longl = q.multi = nullptr; }
     (void)hipFree(c->d_dup); c->d_dup = nullptr;
     c->cap = 0;
 }
@@ -797,6 +849,7 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
         rc |= dalloc(&q.hist, n_tiles * 256);
         rc |= dalloc(&q.chunk, ((n_tiles + kChunkTiles - 1) / kChunkTiles + 1) * 256);
         rc |= dalloc(&q.longl, n / kWalkCap + 16);
+        rc |= dalloc(&q.multi, n / 2 + 16);          // heads of runs with >= 2 entries
     }
     rc |= dalloc(&c->d_dup, n);
     if (rc) { free_buffers(c); return -ENOMEM; }
@@ -844,6 +897,20 @@ int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q,
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// duplicate search over one sorted entry array: run heads -> dense list -> marks (+ long runs)
+template <bool DOUBLE, bool PK>
+void launch_mark(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, const u32* rec, u32 n_entries,
+                 const mgx_sortdedup::Scratch& q, u32* n_multi, u32* n_long, u64 ind_bits, u64 ind_off) {
+    if (!n_entries) return;
+    const u32 per = 256 * kFindItems;
+    hipLaunchKernelGGL((k_find_runs<DOUBLE, PK>), dim3((n_entries + per - 1) / per), dim3(256), 0, s, k1, k2, rec, n_entries,
+                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi);
+    hipLaunchKernelGGL((k_mark_list<DOUBLE, PK>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
+                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, q.longl, n_long);
+    hipLaunchKernelGGL((k_mark_long<DOUBLE, PK>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
+                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.longl, n_long);
 }
 
 }  // namespace
@@ -1030,12 +1097,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
     }
     HIP_TRY(hipEventRecord(c->ev_ind, sN));
-    if (nn) {
-        hipLaunchKernelGGL((k_mark_runs<true, false>), dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[1].longl, &c->d_sc->n_long_n);
-        hipLaunchKernelGGL((k_mark_long<true, false>), dim3(c->n_cu * 2), dim3(256), 0, sN, c->d_nk[ncur], (const u64*)nullptr, c->d_nrec[ncur], nn,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[1].longl, &c->d_sc->n_long_n);
-    }
+    launch_mark<true, false>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
     HIP_TRY(hipEventRecord(c->ev_side[0], sN));
 
     // records by unified coordinate (stable: equal coordinates keep arrival order)
@@ -1090,7 +1152,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     }
     if ((rc = radix_sort(c, s, c->scr[0], c->d_k1, c->d_k2, pk ? nullptr : c->d_prec, nd, 0, bits_of(c->sc.max_k1d), &cur))) return rc;
     if (nd) {
-        const dim3 g((nd + 255) / 256), gl(c->n_cu * 2);
+        const dim3 g((nd + 255) / 256);
         if (tiled) {
             if (pk) hipLaunchKernelGGL((k_indicator_tiles<1, true, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
             else    hipLaunchKernelGGL((k_indicator_tiles<1, false, false>), dim3(n_ind_tiles), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, Lp);
@@ -1098,27 +1160,13 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
             if (pk) hipLaunchKernelGGL((k_set_indicator<1, true>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
             else    hipLaunchKernelGGL((k_set_indicator<1, false>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
         }
-        if (pk) {
-            hipLaunchKernelGGL((k_mark_runs<true, true>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], (const u32*)nullptr, nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
-            hipLaunchKernelGGL((k_mark_long<true, true>), gl, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], (const u32*)nullptr, nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
-        } else {
-            hipLaunchKernelGGL((k_mark_runs<true, false>), g, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
-            hipLaunchKernelGGL((k_mark_long<true, false>), gl, dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd,
-                               c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_d);
-        }
+        if (pk) launch_mark<true, true>(c, s, c->d_k1[cur], c->d_k2[cur], nullptr, nd, c->scr[0], &c->d_sc->n_multi_d, &c->d_sc->n_long_d, ind_bits, ind_off);
+        else    launch_mark<true, false>(c, s, c->d_k1[cur], c->d_k2[cur], c->d_prec[cur], nd, c->scr[0], &c->d_sc->n_multi_d, &c->d_sc->n_long_d, ind_bits, ind_off);
     }
     // singles
     int scur = 0;
     if ((rc = radix_sort(c, s, c->scr[0], c->d_sk1, nullptr, c->d_srec, ns, 0, bits_of(c->sc.max_k1s), &scur))) return rc;
-    if (ns) {
-        hipLaunchKernelGGL((k_mark_runs<false, false>), dim3((ns + 255) / 256), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_s);
-        hipLaunchKernelGGL((k_mark_long<false, false>), dim3(c->n_cu * 2), dim3(256), 0, s, c->d_sk1[scur], (const u64*)nullptr, c->d_srec[scur], ns,
-                           c->d_recs, c->d_indicator, ind_bits, ind_off, c->d_dup, c->scr[0].longl, &c->d_sc->n_long_s);
-    }
+    launch_mark<false, false>(c, s, c->d_sk1[scur], nullptr, c->d_srec[scur], ns, c->scr[0], &c->d_sc->n_multi_s, &c->d_sc->n_long_s, ind_bits, ind_off);
     HIP_TRY(hipStreamWaitEvent(s, c->ev_side[0], 0));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_side[1], 0));
     if (n) hipLaunchKernelGGL(k_count_dup, dim3(c->n_cu * 4), dim3(256), 0, s, c->d_dup, n, c->d_sc);
