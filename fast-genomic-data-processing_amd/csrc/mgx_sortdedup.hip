@@ -70,7 +70,12 @@ struct Scalars {
     alignas(128) u32 n_near;   u32 pad3_[31];
     alignas(128) u32 n_multi_d; u32 n_multi_s, n_multi_n; u32 pad4_[29];   // run heads with more than one entry
 };
-constexpr u64 kNearSpan = 65536;       // near pair: mate 5' end less than this beyond record 1's
+// near pair: mate 5' end less than kNearSpan beyond record 1's (every proper pair; insert sizes are a
+// few hundred bases).  14 delta bits + 2 orientation bits + a 32-bit position = 48 key bits: six
+// 8-bit passes (a 16-bit delta would cost a seventh).
+constexpr int kNearDeltaBits = 14;
+constexpr int kNearShift = kNearDeltaBits + 2;
+constexpr u64 kNearSpan = 1ull << kNearDeltaBits;
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
@@ -114,7 +119,7 @@ struct BuildOut {
     u64 L;
     int packed_coord;                     // ckey = coord << 32 | i (every coordinate < 2^32)
     int packed_pair;                      // dk2 = mate 5' end << 32 | record (every 5' end < 2^32)
-    u64* nk; u32* nrec;                   // near double pairs: one key word p1 << 18 | orient << 16 | (p2 - p1)
+    u64* nk; u32* nrec;                   // near double pairs: one key word p1 << 16 | orient << 14 | (p2 - p1)
     int near_enabled;
 };
 
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
                 m_k1d = max(m_k1d, k1); m_k2d = max(m_k2d, p2);
                 // near pair: the whole (sort_key, mate end) identity fits one word, injectively
                 const bool near = o.near_enabled && p2 - p1 < kNearSpan;
-                const u64 nkey = (p1 << 18) | ((u64)orient << 16) | (p2 - p1);
+                const u64 nkey = (p1 << kNearShift) | ((u64)orient << kNearDeltaBits) | (p2 - p1);
                 c = near ? 3 : 1;
                 wa = near ? nkey : k1;
                 wb = p2;
@@ -541,9 +546,9 @@ __global__ __launch_bounds__(256) void k_indicator_tiles(const u64* __restrict__
     }
 }
 
-// Near pairs (one key word p1 << 18 | orient << 16 | delta, sorted): both ends of every pair in ONE
-// pass.  A pair's record-1 end lies in the tile of p1, its record-2 end at p1 + delta < p1 + 65536 in
-// that tile or the next, so tile t scans the entries with p1 in [t*65536 - 65535, (t+1)*65536).
+// Near pairs (one key word p1 << 16 | orient << 14 | delta, sorted): both ends of every pair in ONE
+// pass.  A pair's record-1 end lies in the tile of p1, its record-2 end at p1 + delta < p1 + kNearSpan in
+// that tile or the next, so tile t scans the entries with p1 in [t*65536 - (kNearSpan - 1), (t+1)*65536).
 // Always the first pass over the bitmap: defines every word.
 __global__ __launch_bounds__(256) void k_indicator_tiles_near(const u64* __restrict__ nk, u32 n, u32* __restrict__ indicator, u64 Lp) {
     __shared__ u32 fw[kIndTile / 32], rv[kIndTile / 32];
@@ -553,15 +558,15 @@ __global__ __launch_bounds__(256) void k_indicator_tiles_near(const u64* __restr
     if (threadIdx.x < 2) {
         const u64 target = threadIdx.x == 0 ? (pos_lo >= kNearSpan - 1 ? pos_lo - (kNearSpan - 1) : 0ull) : pos_hi;
         u32 a = 0, b = n;
-        while (a < b) { const u32 m = a + (b - a) / 2; if ((nk[m] >> 18) < target) a = m + 1; else b = m; }
+        while (a < b) { const u32 m = a + (b - a) / 2; if ((nk[m] >> kNearShift) < target) a = m + 1; else b = m; }
         if (threadIdx.x == 0) s_lo = a; else s_hi = a;
     }
     __syncthreads();
     const u32 lo = s_lo, hi = s_hi;
     for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
         const u64 key = nk[i];
-        const u64 p1 = key >> 18, p2 = p1 + (key & 0xFFFFull);
-        const u32 orient = (u32)(key >> 16) & 3u;
+        const u64 p1 = key >> kNearShift, p2 = p1 + (key & (kNearSpan - 1));
+        const u32 orient = (u32)(key >> kNearDeltaBits) & 3u;
         if (p1 >= pos_lo) {                                  // record 1 forward: FF, FR
             const u32 p = (u32)(p1 - pos_lo);
             atomicOr((orient == 0u || orient == 1u) ? &fw[p >> 5] : &rv[p >> 5], 1u << (p & 31));
@@ -583,8 +588,8 @@ __global__ __launch_bounds__(256) void k_set_indicator_near(const u64* __restric
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const u64 key = nk[i];
-    const u64 p1 = key >> 18, p2 = p1 + (key & 0xFFFFull);
-    const u32 orient = (u32)(key >> 16) & 3u;
+    const u64 p1 = key >> kNearShift, p2 = p1 + (key & (kNearSpan - 1));
+    const u32 orient = (u32)(key >> kNearDeltaBits) & 3u;
     const u64 b1 = p1 + ((orient == 0u || orient == 1u) ? 0ull : L), b2 = p2 + ((orient == 0u || orient == 2u) ? 0ull : L);
     if (b1 < indicator_bits) atomicOr(&indicator[b1 >> 5], 1u << (b1 & 31));
     if (b2 < indicator_bits) atomicOr(&indicator[b2 >> 5], 1u << (b2 & 31));
@@ -595,6 +600,9 @@ __global__ __launch_bounds__(256) void k_set_indicator_near(const u64* __restric
 // ---------------------------------------------------------------------------------------------
 // quality of a pair entry: smaller is better -- score descending, then tile, x, y ascending
 // (main.cpp:253-264 / 303-314); the record index (= arrival order) breaks total ties
+__device__ __forceinline__ u64 quality_word(uint16_t score, const mgx_rec_t& a) {
+    return ((u64)(0xFFFFu - (u32)score) << 48) | ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y;
+}
 __device__ __forceinline__ u64 quality_double(const mgx_rec_t* recs, u32 rec) {
     const mgx_rec_t a = recs[rec];
     const mgx_rec_t b = recs[a.mate];
@@ -675,13 +683,27 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
     for (u32 li = blockIdx.x * 256 + threadIdx.x; li < total; li += gridDim.x * 256) {
         const u32 i = multi_list[li];
         const u64 a1 = k1[i], a2 = K2(i);
-        u32 best = i;
-        u64 bq = DOUBLE ? quality_double(recs, REC(i)) : quality_single(recs, REC(i));
-        u32 j = i + 1;
+        // the first two entries belong to the run by construction: their record gathers (the slow,
+        // random part) are issued together instead of one after the other
+        const u32 r0 = REC(i), r1 = REC(i + 1);
+        const mgx_rec_t ra = recs[r0], rb = recs[r1];
+        u64 q0, q1;
+        if (DOUBLE) {
+            const uint16_t ma = recs[ra.mate].score, mb = recs[rb.mate].score;
+            q0 = quality_word((uint16_t)(ra.score + ma), ra);                 // pair.cpp:81: uint16 sum
+            q1 = quality_word((uint16_t)(rb.score + mb), rb);
+        } else {
+            q0 = quality_word(ra.score, ra); q1 = quality_word(rb.score, rb);
+        }
+        u32 best = i, best_rec = r0;
+        u64 bq = q0;
+        if (q1 < bq || (q1 == bq && r1 < best_rec)) { bq = q1; best = i + 1; best_rec = r1; }
+        u32 j = i + 2;
         for (; j < n && j - i < kWalkCap; ++j) {
             if (k1[j] != a1 || (DOUBLE && K2(j) != a2)) break;
-            const u64 q = DOUBLE ? quality_double(recs, REC(j)) : quality_single(recs, REC(j));
-            if (q < bq || (q == bq && REC(j) < REC(best))) { bq = q; best = j; }
+            const u32 rj = REC(j);
+            const u64 q = DOUBLE ? quality_double(recs, rj) : quality_single(recs, rj);
+            if (q < bq || (q == bq && rj < best_rec)) { bq = q; best = j; best_rec = rj; }
         }
         if (j < n && j - i >= kWalkCap && k1[j] == a1 && (!DOUBLE || K2(j) == a2)) {
             long_list[atomicAdd(n_long, 1u)] = i;                                     // long run: defer
@@ -1075,7 +1097,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     if (!tiled && n) HIP_TRY(hipMemsetAsync(c->d_indicator, 0, (size_t)((c->indicator_bits + 64 + 31) / 32) * 4, s));
 
     // near double pairs (mate 5' end within 65 535 of record 1's -- every proper pair): the whole
-    // (sort_key, mate end) identity is ONE injective key word p1 << 18 | orient << 16 | delta, so one
+    // (sort_key, mate end) identity is ONE injective key word p1 << 16 | orient << 14 | delta, so one
     // LSD sort of (8-byte key, 4-byte record) groups equal pairs: 7 passes x 12 B instead of 9 x 16 B.
     // Runs only need equal keys to be adjacent, not the reference's exact order.
     // The three sorts are independent: near pairs go to side stream 0, records to side stream 1, far
