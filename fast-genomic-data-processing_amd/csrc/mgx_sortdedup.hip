@@ -644,11 +644,17 @@ __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, c
     for (int k = 0; k < kFindItems; ++k) {
         const u32 i = base + k * 256 + threadIdx.x;
         bool multi = false;
+        // neighbours come from the adjacent lanes; only the two edge lanes of a wavefront load theirs
+        const int lane = threadIdx.x & 63;
+        const u64 a1 = i < n ? k1[i] : 0ull, a2 = i < n ? K2(i) : 0ull;
+        u64 p1 = __shfl_up(a1, 1, 64), p2 = DOUBLE ? __shfl_up(a2, 1, 64) : 0ull;
+        u64 n1 = __shfl_down(a1, 1, 64), n2 = DOUBLE ? __shfl_down(a2, 1, 64) : 0ull;
+        if (lane == 0 && i > 0 && i < n) { p1 = k1[i - 1]; p2 = K2(i - 1); }
+        if (lane == 63 && i + 1 < n) { n1 = k1[i + 1]; n2 = K2(i + 1); }
         if (i < n) {
-            const u64 a1 = k1[i], a2 = K2(i);
-            const bool head = i == 0 || k1[i - 1] != a1 || (DOUBLE && K2(i - 1) != a2);
+            const bool head = i == 0 || p1 != a1 || (DOUBLE && p2 != a2);
             if (head) {
-                multi = i + 1 < n && k1[i + 1] == a1 && (!DOUBLE || K2(i + 1) == a2);
+                multi = i + 1 < n && n1 == a1 && (!DOUBLE || n2 == a2);
                 if (!DOUBLE && !multi) {
                     // main.cpp:325-331: the kept single is a duplicate iff a double pair has an end there
                     const u64 target = (a1 >> 2) + (((a1 & 3) == 3) ? L : 0ull);
@@ -780,8 +786,15 @@ __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, c
 }
 
 __global__ __launch_bounds__(256) void k_count_dup(const uint8_t* dup, u32 n, Scalars* sc) {
+    // 16 flag bytes per load (the array comes from hipMalloc: 256-byte aligned); bytes are 0 or 1
     u32 c = 0;
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += dup[i];
+    const u32 n16 = n / 16;
+    const uint4* d4 = reinterpret_cast<const uint4*>(dup);
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) {
+        const uint4 v = d4[i];
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (u32 i = n16 * 16 + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += dup[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&sc->n_dup, c);
