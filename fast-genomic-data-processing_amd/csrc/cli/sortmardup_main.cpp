@@ -81,6 +81,7 @@ void parse_slice(const char* data, size_t lo, size_t hi, const samtext::Header& 
 }  // namespace
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // the three sorts overlap on three streams: keep them on distinct hardware queues
     const char* in_path = nullptr; const char* out_path = nullptr;
     int threads = (int)std::thread::hardware_concurrency();
     int device = 0, level = 6;

@@ -69,6 +69,11 @@ def load():
         raise MgxError(
             f"{path} is missing: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # The sort pipeline overlaps its three sorts on three HIP streams; the runtime maps streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on one queue serialise, which is
+    # what happens once another context (PairHMM, torch) holds streams in the same process.  Only takes
+    # effect if the HIP runtime has not been initialised yet; an explicit setting is respected.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)       # AttributeError if the ABI and the header diverge
