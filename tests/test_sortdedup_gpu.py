@@ -94,6 +94,45 @@ def test_scaled_config_properties(sd_engine, sd_oracle, synth):
     assert dup3.sum() == dup.sum()
 
 
+def test_full_size_properties(sd_engine, synth):
+    """BASELINE.json configs[3] at its full single-GPU size (200 M records, 6.4 GB): the oracle would
+    need minutes, so the result is checked through properties -- a permutation, sorted, stable, mates
+    share their flag, and the number of duplicate PAIRS equals (pairs - distinct pair identities)
+    computed independently with numpy from the 5' ends and strands of the input."""
+    n = 200_000_000
+    recs, L = synth.gen_sortdedup_packed(n, 0x5EED0004)
+    order, dup = sd_engine.sort_mark(L, recs)
+    st = sd_engine.stats()
+    assert st["n_records"] == n and st["n_dup_records"] == int(dup.sum(dtype=np.int64))
+    seen = np.zeros(n, dtype=np.uint8); seen[order] = 1
+    assert seen.all()                                                             # a permutation
+    del seen
+    c = recs["coord"][order]
+    assert np.all(c[1:] >= c[:-1])                                                # sorted
+    same = c[1:] == c[:-1]
+    assert np.all(order[1:][same] > order[:-1][same])                             # stable
+    del c, same
+    m = recs["mate"]; has = m != synth.NO_MATE
+    assert np.array_equal(dup[has], dup[m[has]])                                  # mates share the flag
+    # pair identities as DoublePair defines them (pair.cpp:71-108), record 1 = the lower arrival index
+    first = has & (m > np.arange(n, dtype=np.uint32))
+    a, b = recs[first], recs[m[first]]
+    p1, p2 = a["prime5"].copy(), b["prime5"].copy()
+    f1, f2 = (a["flag"] & 0x10) == 0, (b["flag"] & 0x10) == 0
+    sw = p1 > p2
+    p1[sw], p2[sw] = b["prime5"][sw], a["prime5"][sw]
+    g1 = np.where(sw, f2, f1); g2 = np.where(sw, f1, f2)
+    orient = np.where(g1, np.where(g2, 0, 1), np.where(g2, 2, 3)).astype(np.uint64)
+    orient[(p1 == p2) & (orient == 2)] = 1
+    assert int((p2 - p1).max()) < (1 << 20) and int(p1.max()) < (1 << 40)
+    ident = (p1 << np.uint64(22)) | (orient << np.uint64(20)) | (p2 - p1)
+    n_pairs = len(ident)
+    n_distinct = len(np.unique(ident))
+    dup_pairs = int(dup[first].sum(dtype=np.int64))
+    assert dup_pairs == n_pairs - n_distinct
+    assert st["n_double"] == n_pairs
+
+
 def test_empty_input(sd_engine, synth):
     order, dup = sd_engine.sort_mark(1000, np.zeros(0, dtype=synth.REC_DTYPE))
     assert len(order) == 0 and len(dup) == 0
