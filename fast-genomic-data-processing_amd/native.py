@@ -119,3 +119,29 @@ SORTDEDUP_SYMBOLS = {
     "mgx_sortdedup_sort_mark": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 SYMBOLS.update(SORTDEDUP_SYMBOLS)
+
+
+# ---- include/mgx_smithwaterman.h ---------------------------------------------------------------
+class SwParams(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32)]
+
+
+class SwInput(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("ref_off", C.c_void_p), ("ref", C.c_void_p), ("alt_off", C.c_void_p),
+                ("alt", C.c_void_p), ("strategy", C.c_void_p)]
+
+
+class SwStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("cells", C.c_uint64), ("n_launches", C.c_uint32), ("ms_fill", C.c_float),
+                ("ms_trace", C.c_float), ("backtrace_bytes", C.c_uint64)]
+
+
+SMITHWATERMAN_SYMBOLS = {
+    "mgx_sw_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
+    "mgx_sw_destroy": (None, [C.c_void_p]),
+    "mgx_sw_align_batch": (C.c_int, [C.c_void_p, C.POINTER(SwParams), C.POINTER(SwInput), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "mgx_sw_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint8]),
+    "mgx_sw_stats": (C.c_int, [C.c_void_p, C.POINTER(SwStats)]),
+}
+SYMBOLS.update(SMITHWATERMAN_SYMBOLS)

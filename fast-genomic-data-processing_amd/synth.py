@@ -350,3 +350,41 @@ def gen_sortdedup_packed(n_records, seed, n_contigs=25, contig_len=124_000_000, 
     b["flag"][is_frag] = 1 | 4 | 128
     b["coord"][is_frag] = a["coord"][is_frag]; b["prime5"][is_frag] = a["coord"][is_frag]
     return rec[:n_records] if 2 * n_t >= n_records else rec, L
+
+
+def gen_sw_pairs(n_pairs, seed, ref_range=(40, 400), alt_range=(20, 250), strategies=(9, 10, 11, 12)):
+    """Smith-Waterman workload: reference windows and alternates that are mutated sub-ranges of them
+    (substitutions, insertions, deletions, random flanks), plus a share of unrelated sequences.
+    Returns dict(ref_off, ref, alt_off, alt, strategy) with ASCII bases."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    refs, alts = [], []
+    for _ in range(n_pairs):
+        l1 = int(rng.integers(ref_range[0], ref_range[1] + 1))
+        a = rng.integers(0, 4, l1)
+        kind = rng.integers(0, 8)
+        if kind == 0:
+            b = rng.integers(0, 4, int(rng.integers(alt_range[0], alt_range[1] + 1)))
+        else:
+            want = int(rng.integers(alt_range[0], alt_range[1] + 1))
+            s = int(rng.integers(0, max(1, l1 - 1)))
+            sub = a[s:s + want]
+            rate = (0.0, 0.01, 0.03, 0.08)[int(rng.integers(0, 4))]
+            u = rng.random(len(sub))
+            out = []
+            for ch, x in zip(sub, u):
+                if x < rate / 3:
+                    continue                                   # deletion
+                if x < 2 * rate / 3:
+                    out.append(int(rng.integers(0, 4)))        # insertion before
+                    out.append(int(ch)); continue
+                out.append(int(rng.integers(0, 4)) if x < rate else int(ch))
+            if kind >= 6:                                      # unrelated flanks -> soft clips / overhangs
+                out = list(rng.integers(0, 4, int(rng.integers(0, 12)))) + out + list(rng.integers(0, 4, int(rng.integers(0, 12))))
+            b = np.array(out if out else [0], dtype=np.int64)
+        refs.append(acgt[a]); alts.append(acgt[b])
+    ref_off = np.zeros(n_pairs + 1, dtype=np.uint64); alt_off = np.zeros(n_pairs + 1, dtype=np.uint64)
+    ref_off[1:] = np.cumsum([len(r) for r in refs]); alt_off[1:] = np.cumsum([len(r) for r in alts])
+    strat = np.array(strategies, dtype=np.uint8)[rng.integers(0, len(strategies), n_pairs)]
+    return dict(ref_off=ref_off, ref=np.concatenate(refs) if refs else np.zeros(0, np.uint8), alt_off=alt_off,
+                alt=np.concatenate(alts) if alts else np.zeros(0, np.uint8), strategy=strat)

@@ -161,3 +161,93 @@ def sd_engine(pkg):
     eng = pkg.SortDedupEngine(0)
     yield eng
     eng.close()
+
+
+class SwResultStruct(ctypes.Structure):
+    _fields_ = [("score", ctypes.c_int32), ("max_i", ctypes.c_int32), ("max_j", ctypes.c_int32),
+                ("offset", ctypes.c_int32), ("n_elems", ctypes.c_int32)]
+
+
+class SmithWatermanOracle:
+    """ctypes handle on oracle/libsmithwaterman_oracle.so (CPU restatement; checker only)."""
+
+    def __init__(self):
+        _ensure_oracle()
+        so = os.path.join(ROOT, "oracle", "libsmithwaterman_oracle.so")
+        src = os.path.join(ROOT, "oracle", "smithwaterman_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        self.lib = ctypes.CDLL(so)
+        self.lib.sw_oracle_align.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                                    ctypes.c_int, ctypes.c_void_p]
+
+    def align(self, ref, alt, params, strategy, cap=None):
+        """-> (cigar bytes, offset, score)"""
+        ref = np.ascontiguousarray(ref, dtype=np.uint8); alt = np.ascontiguousarray(alt, dtype=np.uint8)
+        cap = 2 * max(len(ref), len(alt)) if cap is None else cap
+        res = SwResultStruct()
+        el = np.zeros(2 * (len(ref) + len(alt) + 4), dtype=np.int16)
+        out = ctypes.create_string_buffer(cap + 8)
+        n = ctypes.c_int32()
+        rc = self.lib.sw_oracle_align(*[int(x) for x in params], ref.ctypes.data, len(ref), alt.ctypes.data, len(alt), int(strategy),
+                                      ctypes.byref(res), el.ctypes.data, out, cap, ctypes.byref(n))
+        assert rc == 0
+        return out.raw[:n.value], res.offset, res.score
+
+    def batch(self, w, params):
+        """w: dict from synth.gen_sw_pairs -> (cigars, offsets, scores)"""
+        cig, off, sc = [], [], []
+        for p in range(len(w["strategy"])):
+            c, o, s = self.align(w["ref"][int(w["ref_off"][p]):int(w["ref_off"][p + 1])],
+                                 w["alt"][int(w["alt_off"][p]):int(w["alt_off"][p + 1])], params, w["strategy"][p])
+            cig.append(c); off.append(o); sc.append(s)
+        return cig, np.array(off, dtype=np.int32), np.array(sc, dtype=np.int32)
+
+
+class SmithWatermanRef:
+    """The reference's own AVX2 aligner compiled in place (oracle/_ref/libref_smithwaterman.so)."""
+
+    def __init__(self, so):
+        self.lib = ctypes.CDLL(so)
+        self.lib.ref_sw_align.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.ref_sw_batch.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p]
+
+    def align(self, ref, alt, params, strategy, cap=None):
+        ref = np.ascontiguousarray(ref, dtype=np.uint8); alt = np.ascontiguousarray(alt, dtype=np.uint8)
+        cap = 2 * max(len(ref), len(alt)) if cap is None else cap
+        cig = ctypes.create_string_buffer(cap + 8)
+        cnt = ctypes.c_uint32(); off = ctypes.c_int32()
+        rc = self.lib.ref_sw_align(*[int(x) for x in params], ref.ctypes.data, len(ref), alt.ctypes.data, len(alt), int(strategy),
+                                   cig, cap, ctypes.byref(cnt), ctypes.byref(off))
+        assert rc == 0
+        return cig.value, off.value
+
+    def batch(self, w, params, stride):
+        n = len(w["strategy"])
+        cig = np.zeros((n, stride), dtype=np.uint8); off = np.zeros(n, dtype=np.int32)
+        keep = [np.ascontiguousarray(w[k]) for k in ("ref_off", "ref", "alt_off", "alt", "strategy")]
+        rc = self.lib.ref_sw_batch(*[int(x) for x in params], n, *[a.ctypes.data for a in keep], cig.ctypes.data, stride, off.ctypes.data)
+        assert rc == 0
+        return cig, off
+
+
+@pytest.fixture(scope="session")
+def sw_oracle():
+    return SmithWatermanOracle()
+
+
+@pytest.fixture(scope="session")
+def sw_ref():
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_smithwaterman.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_smithwaterman.so not built (needs /root/reference)")
+    return SmithWatermanRef(so)
+
+
+@pytest.fixture(scope="session")
+def sw_engine(pkg):
+    eng = pkg.SmithWatermanEngine(0)
+    yield eng
+    eng.close()

@@ -1,4 +1,4 @@
-"""The boundary is a C ABI: both headers must compile as plain C99 (no C++ types, no torch types),
+"""The boundary is a C ABI: all headers must compile as plain C99 (no C++ types, no torch types),
 and a C program must link against libmgx.so using nothing but them."""
 import os
 import subprocess
@@ -12,14 +12,19 @@ def test_headers_compile_as_c99_and_link(tmp_path, pkg):
     src.write_text("""
 #include "mgx_pairhmm.h"
 #include "mgx_sortdedup.h"
+#include "mgx_smithwaterman.h"
 #include <stdio.h>
 int main(void) {
-    mgx_pairhmm_t* p = 0; mgx_sortdedup_t* s = 0;
+    mgx_pairhmm_t* p = 0; mgx_sortdedup_t* s = 0; mgx_sw_t* w = 0;
+    mgx_sw_params_t swp; mgx_sw_input_t swi; mgx_sw_stats_t sws; (void)swp; (void)swi; (void)sws;
     mgx_pairhmm_input_t in; mgx_rec_t rec; mgx_raw_records_t raw; mgx_pairhmm_stats_t st; mgx_sortdedup_stats_t ss;
     (void)in; (void)rec; (void)raw; (void)st; (void)ss;
     if (sizeof(mgx_rec_t) != 32) return 3;
     int a = mgx_pairhmm_create(0, 0, &p);          /* -ENODEV without a GPU, 0 with one */
     int b = mgx_sortdedup_create(0, 0, &s);
+    int c = mgx_sw_create(0, 0, &w);
+    if (c != a) return 4;
+    if (w) mgx_sw_destroy(w);
     printf("%d %d %s\\n", a, b, mgx_last_error());
     if (p) mgx_pairhmm_destroy(p);
     if (s) mgx_sortdedup_destroy(s);

@@ -1,0 +1,72 @@
+"""GPU parity tests of the Smith-Waterman path (row F4) through the C ABI, against the oracle and the
+golden vectors of the reference's own aligner.  Bar: CIGAR text and offset identical."""
+import os
+
+import numpy as np
+import pytest
+
+from test_smithwaterman_oracle import cig_bytes, load_gold
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_vectors(sw_engine):
+    for k in range(3):
+        w, params, cig, off = load_gold(k)
+        got_c, got_o = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"], params)
+        assert np.array_equal(got_o, off)
+        assert got_c == [cig_bytes(r) for r in cig]
+
+
+@pytest.mark.parametrize("ref_range,alt_range,n", [((1, 64), (1, 64), 1500), ((60, 130), (20, 150), 800),
+                                                   ((250, 520), (100, 300), 300), ((900, 1100), (50, 400), 60),
+                                                   ((1500, 2048), (100, 300), 20)])
+def test_random_vs_oracle(sw_engine, sw_oracle, synth, ref_range, alt_range, n):
+    """every row class of the fill kernel (1, 2, 4, 8, 16, 32 rows per lane), all strategies"""
+    for seed, params in ((11, (25, -50, -110, -6)), (12, (3, -1, -4, -3))):
+        w = synth.gen_sw_pairs(n, seed + ref_range[0], ref_range=ref_range, alt_range=alt_range)
+        want_c, want_o, want_s = sw_oracle.batch(w, params)
+        got_c, got_o, got_s = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"], params, want_score=True)
+        assert np.array_equal(got_o, want_o)
+        assert np.array_equal(got_s, want_s)
+        assert got_c == want_c
+
+
+def test_single_pair_entry_point(sw_engine, sw_oracle):
+    """mgx_sw_align == SmithWaterman_align argument for argument, including short text buffers"""
+    ref = np.frombuffer(b"ACGTACGTAAACCCGGGTTTACGATCGATCGGCTA", dtype=np.uint8)
+    alt = np.frombuffer(b"TTACGTTTACGTAAACGGGTTACGATGATCGGC", dtype=np.uint8)
+    for st in (9, 10, 11, 12):
+        for cap in (None, 3, 6):
+            want_c, want_o, _ = sw_oracle.align(ref, alt, (25, -50, -110, -6), st, cap=cap)
+            got_c, got_o = sw_engine.align(ref.tobytes(), alt.tobytes(), (25, -50, -110, -6), st, cigar_length=cap)
+            assert got_c == want_c and got_o == want_o
+
+
+def test_mixed_classes_keep_input_order(sw_engine, sw_oracle, synth):
+    """pairs of different row classes interleaved: results come back in input order"""
+    parts = [synth.gen_sw_pairs(40, 70 + k, ref_range=r, alt_range=(10, 90)) for k, r in enumerate(((5, 60), (300, 500), (70, 120), (1000, 1300)))]
+    order = np.random.default_rng(5).permutation(160)
+    refs, alts, strat = [], [], []
+    for q in order:
+        w = parts[q // 40]; p = q % 40
+        refs.append(w["ref"][int(w["ref_off"][p]):int(w["ref_off"][p + 1])]); alts.append(w["alt"][int(w["alt_off"][p]):int(w["alt_off"][p + 1])])
+        strat.append(w["strategy"][p])
+    ro = np.zeros(161, dtype=np.uint64); ao = np.zeros(161, dtype=np.uint64)
+    ro[1:] = np.cumsum([len(r) for r in refs]); ao[1:] = np.cumsum([len(r) for r in alts])
+    w = dict(ref_off=ro, ref=np.concatenate(refs), alt_off=ao, alt=np.concatenate(alts), strategy=np.array(strat, dtype=np.uint8))
+    want_c, want_o, _ = sw_oracle.batch(w, (25, -50, -110, -6))
+    got_c, got_o = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"])
+    assert np.array_equal(got_o, want_o) and got_c == want_c
+
+
+def test_limits_are_errors_not_faults(pkg, sw_engine):
+    z = np.zeros(3000, dtype=np.uint8) + 65
+    with pytest.raises(pkg.MgxError):       # reference longer than 2048
+        sw_engine.align_batch([0, 2049], z[:2049], [0, 10], z[:10], [9])
+    with pytest.raises(pkg.MgxError):       # empty alternate
+        sw_engine.align_batch([0, 10], z[:10], [0, 0], z[:0], [9])
+    with pytest.raises(pkg.MgxError):       # unknown strategy
+        sw_engine.align_batch([0, 10], z[:10], [0, 10], z[:10], [3])
+    c, o = sw_engine.align_batch(np.zeros(1, np.uint64), z[:0], np.zeros(1, np.uint64), z[:0], np.zeros(0, np.uint8))
+    assert c == [] and len(o) == 0
