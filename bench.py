@@ -161,6 +161,50 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backe
     return out
 
 
+
+def smithwaterman_leg(pkg, synth, args, rank, local_rank):
+    """Row F4 (widening, not part of BASELINE.json's metric): reads against their best haplotype, the
+    batch Mutect2Cpp realigns after PairHMM.  Rank 0 only; reported next to the headline numbers."""
+    if rank != 0:
+        return None
+    n = args.sw_pairs
+    w = synth.gen_sw_pairs(n, 0x5EED0020, ref_range=(250, 400), alt_range=(100, 151), strategies=(9,))
+    eng = pkg.SmithWatermanEngine(local_rank)
+    eng.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"])
+    fills, traces = [], []
+    for _ in range(3):
+        cig, off = eng.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"])
+        st = eng.stats(); fills.append(st["ms_fill"]); traces.append(st["ms_trace"])
+    ms_fill, ms_trace = float(np.median(fills)), float(np.median(traces))
+    out = {"metric": "Smith-Waterman GCUPS (matrix fill + back-trace on the device, inputs resident)",
+           "value": st["cells"] / (ms_fill + ms_trace) / 1e6, "unit": "GCUPS", "dtype": "i32",
+           "config": {"workload": "synthetic reads (100-151 bases) against haplotype windows (250-400 bases), STANDARD_NGS "
+                                  "parameters, SOFTCLIP", "pairs": n, "cells": st["cells"]},
+           "ms_fill": ms_fill, "ms_trace": ms_trace, "backtrace_bytes": st["backtrace_bytes"]}
+    if not args.no_cpu_baseline:
+        so = os.path.join(ROOT, "oracle", "_ref", "libref_smithwaterman.so")
+        if os.path.exists(so):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from conftest import SmithWatermanRef
+            ref = SmithWatermanRef(so)
+            m = n
+            sub = dict(ref_off=w["ref_off"][:m + 1], ref=w["ref"], alt_off=w["alt_off"][:m + 1], alt=w["alt"], strategy=w["strategy"][:m])
+            dts = []
+            for _ in range(5):                      # the first call pays the page faults of its per-call 4 MB matrices
+                t0 = time.perf_counter()
+                rc, ro = ref.batch(sub, (25, -50, -110, -6), 2 * 400 + 1)
+                dts.append(time.perf_counter() - t0)
+            dt = float(np.median(dts))
+            cells = float((np.diff(sub["ref_off"].astype(np.int64)) * np.diff(sub["alt_off"].astype(np.int64))).sum())
+            lens = (rc != 0).sum(axis=1)
+            same = all(rc[p, :lens[p]].tobytes() == cig[p] for p in range(m)) and bool(np.array_equal(ro, off[:m]))
+            out["cpu_baseline"] = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": host_cores(), "kind": "reference",
+                                   "sample": f"the same {m} pairs, reference AVX2 aligner (one call per pair, OpenMP over pairs), median of 5 runs, {dt:.3f} s",
+                                   "identical_to_device": same}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +215,7 @@ def main():
     ap.add_argument("--sort-records", type=int, default=200_000_000,
                     help="records per GPU for the sortmardup leg (BASELINE.json configs[3]); 0 disables it")
     ap.add_argument("--sort-steps", type=int, default=5)
+    ap.add_argument("--sw-pairs", type=int, default=20000, help="Smith-Waterman pairs (row F4 leg; 0 skips it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -270,9 +315,12 @@ def main():
     sort_line = None
     if args.sort_records > 0:
         sort_line = sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend)
+    sw_line = smithwaterman_leg(pkg, synth, args, rank, local_rank) if args.sw_pairs > 0 else None
     if rank == 0:
         if sort_line is not None:
             line["sortmardup"] = sort_line
+        if sw_line is not None:
+            line["smithwaterman"] = sw_line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -43,7 +43,9 @@ class SmithWatermanEngine:
         score = np.zeros(n, dtype=np.int32)
         native.check(self.lib.mgx_sw_align_batch(self.ctx, C.byref(P), C.byref(inp), _ptr(off), _ptr(cig), stride,
                                                  _ptr(score) if want_score else None))
-        cigars = [bytes(row[:int(np.argmax(row == 0))]) if (row == 0).any() else bytes(row) for row in cig]
+        lens = (cig != 0).sum(axis=1)                    # the text holds no NUL before its end
+        flat = cig.tobytes()
+        cigars = [flat[p * stride:p * stride + int(lens[p])] for p in range(n)]
         return (cigars, off, score) if want_score else (cigars, off)
 
     def align(self, ref, alt, params=STANDARD_NGS, strategy=SOFTCLIP, cigar_length=None):
