@@ -61,7 +61,8 @@ struct SwParams { int match, mismatch, open, extend; };
 template <int RPL>
 __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, const u8* __restrict__ s1, const u8* __restrict__ s2,
                                                 u8* __restrict__ bt, int32_t* __restrict__ sc, SwParams P) {
-    const SwJob J = jobs[blockIdx.x];
+    extern __shared__ u8 sh_b[];                      // the alternate sequence: one global load per step would
+    const SwJob J = jobs[blockIdx.x];                 // put ~200 serial HBM latencies on every wavefront's path
     const int lane = threadIdx.x;
     const int nrow = (int)J.len1, ncol = (int)J.len2;
     const bool indel = J.strategy == MGX_SW_INDEL || J.strategy == MGX_SW_LEADING_INDEL;
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
     int32_t* last_row = sc + J.sc_off;
     int32_t* last_col = last_row + ncol + 1;
     u8* btp = bt + J.bt_off;
+    for (int x = lane; x < ncol; x += 64) sh_b[x] = b[x];
+    __syncthreads();
     const int r0 = lane * RPL;                       // this lane owns rows r0+1 .. r0+RPL (1-based)
     int sa[RPL], hl[RPL], e[RPL];
 #pragma unroll
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
                 diag = j == 1 ? 0 : (indel ? P.open + (j - 2) * P.extend : 0);            // H(0, j-1), H(0,0) = 0
             } else { up_h = rh; up_f = rf; diag = diag_in; }
             diag_in = up_h;                                          // H(r0, j) is the diagonal of column j+1
-            const int c2 = (int)b[j - 1];
+            const int c2 = (int)sh_b[j - 1];
             u32 packed[(RPL + 3) / 4];
 #pragma unroll
             for (int q = 0; q < (RPL + 3) / 4; ++q) packed[q] = 0;
@@ -260,8 +263,8 @@ namespace {
 constexpr u64 kArenaLimit = 12ull << 30;      // back-trace bytes per chunk of a batch
 
 template <int RPL>
-void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, SwParams P) {
-    hipLaunchKernelGGL((k_sw_fill<RPL>), dim3(n), dim3(64), 0, c->stream, jobs, c->d_s1.p, c->d_s2.p, c->d_bt.p, c->d_sc.p, P);
+void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, u32 max_len2, SwParams P) {
+    hipLaunchKernelGGL((k_sw_fill<RPL>), dim3(n), dim3(64), (max_len2 + 15) & ~15u, c->stream, jobs, c->d_s1.p, c->d_s2.p, c->d_bt.p, c->d_sc.p, P);
 }
 
 // pairs [lo, hi) of the input, already validated
@@ -296,15 +299,16 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
     HIP_TRY(hipEventRecord(c->ev[0], s));
     for (u32 a = 0; a < n;) {
         u32 b = a;
-        while (b < n && jobs[b].rpl == jobs[a].rpl) ++b;
+        u32 m2 = 0;
+        while (b < n && jobs[b].rpl == jobs[a].rpl) { m2 = std::max(m2, jobs[b].len2); ++b; }
         const SwJob* dj = c->d_jobs.p + a;
         switch (jobs[a].rpl) {
-            case 1: launch_fill<1>(c, dj, b - a, P); break;
-            case 2: launch_fill<2>(c, dj, b - a, P); break;
-            case 4: launch_fill<4>(c, dj, b - a, P); break;
-            case 8: launch_fill<8>(c, dj, b - a, P); break;
-            case 16: launch_fill<16>(c, dj, b - a, P); break;
-            default: launch_fill<32>(c, dj, b - a, P); break;
+            case 1: launch_fill<1>(c, dj, b - a, m2, P); break;
+            case 2: launch_fill<2>(c, dj, b - a, m2, P); break;
+            case 4: launch_fill<4>(c, dj, b - a, m2, P); break;
+            case 8: launch_fill<8>(c, dj, b - a, m2, P); break;
+            case 16: launch_fill<16>(c, dj, b - a, m2, P); break;
+            default: launch_fill<32>(c, dj, b - a, m2, P); break;
         }
         c->stats.n_launches++;
         a = b;

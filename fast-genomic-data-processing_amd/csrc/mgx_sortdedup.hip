@@ -100,16 +100,9 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* sm, u32* total) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// build: classify records, count entries per 1024-record block
+// build: classify records, emit pair entries and coordinate keys
 // ---------------------------------------------------------------------------------------------
 constexpr int kBuildBlock = 2048;
-
-__device__ __forceinline__ int classify(const mgx_rec_t& r, u32 i) {
-    // 0 = no entry, 1 = record 1 of a double pair, 2 = single pair
-    if (r.flag & kIgnorable) return 0;
-    if (r.mate == MGX_NO_MATE) return 2;
-    return r.mate > i ? 1 : 0;
-}
 
 struct BuildOut {
     u64* ckey; u32* cval;                 // coordinate sort input
