@@ -20,6 +20,7 @@
 #include <cerrno>
 #include <climits>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -260,7 +261,7 @@ struct mgx_sw {
 };
 
 namespace {
-constexpr u64 kArenaLimit = 12ull << 30;      // back-trace bytes per chunk of a batch
+constexpr u64 kArenaLimit = 12ull << 30;      // back-trace bytes per chunk of a batch (MGX_SW_ARENA_LIMIT overrides, for tests)
 
 template <int RPL>
 void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, u32 max_len2, SwParams P) {
@@ -400,13 +401,15 @@ static int align_impl(mgx_sw_t* c, const mgx_sw_params_t* params, const mgx_sw_i
         if (st < MGX_SW_SOFTCLIP || st > MGX_SW_IGNORE) { set_error("pair %llu: unknown overhang strategy %d", (unsigned long long)p, st); return -EINVAL; }
     }
     HIP_TRY(hipSetDevice(c->device));
+    u64 limit = kArenaLimit;
+    if (const char* e = getenv("MGX_SW_ARENA_LIMIT")) { const long long v = atoll(e); if (v > 0) limit = (u64)v; }
     u64 lo = 0;
     while (lo < in->n_pairs) {
         u64 hi = lo, bt = 0;
         while (hi < in->n_pairs) {
             const u64 l1 = in->ref_off[hi + 1] - in->ref_off[hi], l2 = in->alt_off[hi + 1] - in->alt_off[hi];
             const u64 r = (u64)rpl_for((int)l1), need = (l2 + (l1 + r - 1) / r + 1) * 64 * r + 16;
-            if (hi > lo && bt + need > kArenaLimit) break;
+            if (hi > lo && bt + need > limit) break;
             bt += need; ++hi;
         }
         const int rc = run_chunk(c, params, in, lo, hi, out_offset, out_cigar, cigar_stride, out_score, cap_override);

@@ -60,6 +60,16 @@ def test_mixed_classes_keep_input_order(sw_engine, sw_oracle, synth):
     assert np.array_equal(got_o, want_o) and got_c == want_c
 
 
+def test_batches_larger_than_the_arena_are_chunked(sw_engine, sw_oracle, synth, monkeypatch):
+    """a batch whose back-trace matrices exceed the arena is processed in several chunks"""
+    w = synth.gen_sw_pairs(300, 91, ref_range=(40, 300), alt_range=(20, 150))
+    want_c, want_o, _ = sw_oracle.batch(w, (25, -50, -110, -6))
+    monkeypatch.setenv("MGX_SW_ARENA_LIMIT", str(1 << 20))          # about a dozen pairs per chunk
+    got_c, got_o = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"])
+    assert np.array_equal(got_o, want_o) and got_c == want_c
+    assert sw_engine.stats()["n_launches"] > 10
+
+
 def test_limits_are_errors_not_faults(pkg, sw_engine):
     z = np.zeros(3000, dtype=np.uint8) + 65
     with pytest.raises(pkg.MgxError):       # reference longer than 2048
