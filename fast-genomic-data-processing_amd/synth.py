@@ -207,7 +207,7 @@ class RawRecords:
 
 def gen_sortdedup_raw(n_templates, seed, n_contigs=5, contig_len=200_000, read_len=100, dup_rate=0.15,
                       frag_rate=0.05, supp_rate=0.03, clip_rate=0.2, unmapped_pair_rate=0.01,
-                      cross_contig_rate=0.02, qname_style="illumina7"):
+                      cross_contig_rate=0.02, qname_style="illumina7", ins_range=(200, 600)):
     """A queryname-grouped synthetic SAM body in parsed form (BASELINE.json configs[3] in miniature):
     proper pairs in all four orientations, soft/hard clips on both strands, fragments whose mate
     is unmapped, supplementary records between mates, both-unmapped pairs, cross-contig pairs and
@@ -271,7 +271,7 @@ def gen_sortdedup_raw(n_templates, seed, n_contigs=5, contig_len=200_000, read_l
             tid1 = int(rng.randint(n_contigs))
             s1 = int(rng.randint(1000, contig_len - 2000))
             o = rng.rand()
-            ins = int(rng.randint(200, 600))
+            ins = int(rng.randint(ins_range[0], ins_range[1]))
             tid2 = int(rng.randint(n_contigs)) if rng.rand() < cross_contig_rate else tid1
             if o < 0.85:   r1, r2, s2 = False, True, s1 + ins          # FR
             elif o < 0.90: r1, r2, s2 = True, False, s1 + ins          # RF

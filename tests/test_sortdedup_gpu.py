@@ -23,6 +23,8 @@ def test_golden_file(pkg, sd_engine):
 @pytest.mark.parametrize("n_templates,seed,kw", [
     (3000, 21, {}), (20000, 22, dict(dup_rate=0.5)), (5000, 23, dict(qname_style="plain")),   # total ties
     (7, 24, {}), (1, 25, {}), (40000, 26, dict(n_contigs=2, contig_len=5000, dup_rate=0.0)),   # dense: long runs
+    # inserts on both sides of the near-pair span (16 384): one-word and two-word pair keys side by side
+    (30000, 27, dict(n_contigs=3, contig_len=400_000, ins_range=(8000, 40000), dup_rate=0.3)),
 ])
 def test_raw_random_vs_oracle(pkg, sd_engine, sd_oracle, synth, n_templates, seed, kw):
     raw = synth.gen_sortdedup_raw(n_templates, seed, **kw)
