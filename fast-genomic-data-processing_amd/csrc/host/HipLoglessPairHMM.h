@@ -6,6 +6,7 @@
 //   initialize()               haplotype table + haplotype -> index map; is_use_trietree_optimize
 //                              is always false (the trie is a CPU-only saving with identical
 //                              results)
+//   enqueue() / flush()        the same for several active regions in one device batch (row F1)
 //   computeLog10Likelihoods()  per read: the four quality arrays (&127 like ReadForPairHMM.cpp:34-36),
 //                              de-duplication of identical reads (same bases and same four arrays),
 //                              one test case per (unique read, haplotype), ONE batched call into
@@ -79,14 +80,71 @@ public:
     void computeLog10Likelihoods(Matrix* logLikelihoods, std::vector<std::shared_ptr<Read>>& processedReads,
                                  GcpMap* gcp) {
         if (processedReads.empty()) return;
-        const int n_reads = (int)processedReads.size();
-        const int n_haps = (int)hap_off_.size() - 1;
+        Prepared p = prepare(logLikelihoods, processedReads, gcp);
+        mgx_pairhmm_input_t in = p.input();
+        if (mgx_pairhmm_compute(ctx_, &in, p.out.data()) != 0)
+            throw std::runtime_error(std::string("mgx_pairhmm_compute: ") + mgx_last_error());
+        scatter(p);
+    }
+
+    // SURVEY.md 8f row F1 -- region-level batching inside the caller: enqueue() does everything
+    // computeLog10Likelihoods does up to the native call (for the haplotypes of the latest initialize())
+    // and parks the region; flush() sends every parked region to the device as ONE batch
+    // (mgx_pairhmm_compute_regions) and fills the matrices.  A worker can therefore assemble the next
+    // regions while earlier ones wait, and small regions no longer pay a device round trip each
+    // (1000 regions of 40 x 25: 163 us per region one at a time, 29 us in one batch).
+    // The matrices must stay alive until flush().
+    void enqueue(Matrix* logLikelihoods, std::vector<std::shared_ptr<Read>>& processedReads, GcpMap* gcp) {
+        if (processedReads.empty()) return;
+        queue_.push_back(prepare(logLikelihoods, processedReads, gcp));
+    }
+    size_t queued() const { return queue_.size(); }
+    void flush() {
+        if (queue_.empty()) return;
+        std::vector<mgx_pairhmm_input_t> ins;
+        std::vector<double*> outs;
+        for (auto& p : queue_) { ins.push_back(p.input()); outs.push_back(p.out.data()); }
+        const int rc = mgx_pairhmm_compute_regions(ctx_, (uint32_t)ins.size(), ins.data(), outs.data());
+        if (rc != 0) { queue_.clear(); throw std::runtime_error(std::string("mgx_pairhmm_compute_regions: ") + mgx_last_error()); }
+        for (auto& p : queue_) scatter(p);
+        queue_.clear();
+    }
+
+    // the reference calls the _trie variants only when is_use_trietree_optimize is true; they are
+    // provided so the virtual interface is complete and return the same values
+    void computeLog10Likelihoods_trie(Matrix* m, std::vector<std::shared_ptr<Read>>& r, GcpMap* g) { computeLog10Likelihoods(m, r, g); }
+    void computeLog10Likelihoods_trie_unique(Matrix* m, std::vector<std::shared_ptr<Read>>& r, GcpMap* g) { computeLog10Likelihoods(m, r, g); }
+
+private:
+    // one region, ready for the native call: unique reads x the haplotype table of its initialize()
+    struct Prepared {
+        Matrix* matrix = nullptr;
+        int n_reads = 0, n_haps = 0;
+        std::vector<uint64_t> read_off{0}, hap_off;
+        std::vector<uint8_t> bases, qual, ins, del, gc, hap_bases;
+        std::vector<int> unique_of;
+        std::unordered_map<const Haplotype*, int> hap_index;
+        std::vector<double> out;
+        mgx_pairhmm_input_t input() const {
+            mgx_pairhmm_input_t in{};
+            in.n_reads = read_off.size() - 1; in.read_off = read_off.data();
+            in.bases = bases.data(); in.qual = qual.data(); in.ins = ins.data(); in.del = del.data(); in.gcp = gc.data();
+            in.n_haps = (uint64_t)n_haps; in.hap_off = hap_off.data(); in.hap_bases = hap_bases.data();
+            in.n_pairs = in.n_reads * in.n_haps; in.pair_read = nullptr; in.pair_hap = nullptr;
+            return in;
+        }
+    };
+
+    Prepared prepare(Matrix* logLikelihoods, std::vector<std::shared_ptr<Read>>& processedReads, GcpMap* gcp) {
+        Prepared p;
+        p.matrix = logLikelihoods;
+        p.n_reads = (int)processedReads.size();
+        p.n_haps = (int)hap_off_.size() - 1;
+        p.hap_off = hap_off_; p.hap_bases = hap_bases_; p.hap_index = hap_index_;
         // ---- unique reads (VectorLoglessPairHMM.cpp:71-104): key = quals (masked) + bases
-        std::vector<uint64_t> read_off(1, 0);
-        std::vector<uint8_t> bases, qual, ins, del, gc;
-        std::vector<int> unique_of(n_reads);
+        p.unique_of.resize(p.n_reads);
         std::unordered_map<std::string, int> seen;
-        for (int r = 0; r < n_reads; ++r) {
+        for (int r = 0; r < p.n_reads; ++r) {
             const auto& rd = processedReads[r];
             const int len = Traits::read_len(*rd);
             auto iq = Traits::ins_quals(rd, len);
@@ -102,44 +160,36 @@ public:
                 key[4 * len + k] = (char)b[k];
             }
             auto it = seen.find(key);
-            if (it != seen.end()) { unique_of[r] = it->second; continue; }
-            const int u = (int)read_off.size() - 1;
+            if (it != seen.end()) { p.unique_of[r] = it->second; continue; }
+            const int u = (int)p.read_off.size() - 1;
             seen.emplace(std::move(key), u);
-            unique_of[r] = u;
-            bases.insert(bases.end(), b, b + len);
-            qual.insert(qual.end(), q, q + len);
-            ins.insert(ins.end(), iq.get(), iq.get() + len);
-            del.insert(del.end(), dq.get(), dq.get() + len);
-            gc.insert(gc.end(), (const uint8_t*)g, (const uint8_t*)g + len);
-            read_off.push_back(bases.size());
+            p.unique_of[r] = u;
+            p.bases.insert(p.bases.end(), b, b + len);
+            p.qual.insert(p.qual.end(), q, q + len);
+            p.ins.insert(p.ins.end(), iq.get(), iq.get() + len);
+            p.del.insert(p.del.end(), dq.get(), dq.get() + len);
+            p.gc.insert(p.gc.end(), (const uint8_t*)g, (const uint8_t*)g + len);
+            p.read_off.push_back(p.bases.size());
         }
-        const int n_unique = (int)read_off.size() - 1;
-        // ---- one test case per (unique read, haplotype), read-major like uniqueTestcases: the
-        //      cross-product form of the ABI (pair arrays NULL), out[u * n_haps + h]
-        mgx_pairhmm_input_t in{};
-        in.n_reads = n_unique; in.read_off = read_off.data();
-        in.bases = bases.data(); in.qual = qual.data(); in.ins = ins.data(); in.del = del.data(); in.gcp = gc.data();
-        in.n_haps = n_haps; in.hap_off = hap_off_.data(); in.hap_bases = hap_bases_.data();
-        in.n_pairs = (uint64_t)n_unique * n_haps; in.pair_read = nullptr; in.pair_hap = nullptr;
-        std::vector<double> out((size_t)n_unique * n_haps);
-        if (mgx_pairhmm_compute(ctx_, &in, out.data()) != 0)
-            throw std::runtime_error(std::string("mgx_pairhmm_compute: ") + mgx_last_error());
-        // ---- scatter (VectorLoglessPairHMM.cpp:135-146)
-        for (int r = 0; r < n_reads; ++r) {
+        // one test case per (unique read, haplotype), read-major like uniqueTestcases: the
+        // cross-product form of the ABI (pair arrays NULL), out[u * n_haps + h]
+        p.out.resize((p.read_off.size() - 1) * (size_t)p.n_haps);
+        return p;
+    }
+
+    // VectorLoglessPairHMM.cpp:135-146
+    static void scatter(Prepared& p) {
+        for (int r = 0; r < p.n_reads; ++r) {
             int hapIdx = 0;
-            for (auto& haplotype : Traits::alleles(*logLikelihoods)) {
-                const int idx = hap_index_.at(haplotype.get());
-                Traits::set(*logLikelihoods, hapIdx, r, out[(size_t)unique_of[r] * n_haps + idx]);
+            for (auto& haplotype : Traits::alleles(*p.matrix)) {
+                const int idx = p.hap_index.at(haplotype.get());
+                Traits::set(*p.matrix, hapIdx, r, p.out[(size_t)p.unique_of[r] * p.n_haps + idx]);
                 hapIdx++;
             }
         }
     }
-    // the reference calls the _trie variants only when is_use_trietree_optimize is true; they are
-    // provided so the virtual interface is complete and return the same values
-    void computeLog10Likelihoods_trie(Matrix* m, std::vector<std::shared_ptr<Read>>& r, GcpMap* g) { computeLog10Likelihoods(m, r, g); }
-    void computeLog10Likelihoods_trie_unique(Matrix* m, std::vector<std::shared_ptr<Read>>& r, GcpMap* g) { computeLog10Likelihoods(m, r, g); }
 
-private:
+    std::vector<Prepared> queue_;
     mgx_pairhmm_t* ctx_ = nullptr;
     std::vector<uint64_t> hap_off_{0};
     std::vector<uint8_t> hap_bases_;

@@ -446,6 +446,167 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
     return 0;
 }
 
+// Row F1: the cross-product test cases of several regions in one batch -- one upload, one set of
+// launches, one download.  Host work is linear in reads + haplotypes (the test cases are enumerated
+// on the device), so coalescing a thousand small regions costs microseconds, not a pair list.
+int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_input_t* regs, mgx_pairhmm_batch* b,
+                       std::vector<uint64_t>* out_base) {
+    uint64_t nr = 0, nh = 0, n = 0, read_bytes = 0, hap_bytes = 0;
+    out_base->assign(n_regions + 1, 0);
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        const mgx_pairhmm_input_t& in = regs[g];
+        if (in.pair_read || in.pair_hap) { set_error("region %u: regions are given in the cross-product form (pair arrays NULL)", g); return -EINVAL; }
+        nr += in.n_reads; nh += in.n_haps; n += in.n_reads * in.n_haps;
+        if (in.n_reads) read_bytes += in.read_off[in.n_reads] - in.read_off[0];
+        if (in.n_haps) hap_bytes += in.hap_off[in.n_haps] - in.hap_off[0];
+        (*out_base)[g + 1] = n;
+    }
+    if (n > 0xFFFFFFF0ull || nr > 0xFFFFFFF0ull) { set_error("more than 2^32 test cases in one batch"); return -E2BIG; }
+    b->n_pairs = n;
+    b->stats.n_pairs = n;
+    if (n == 0) return 0;
+    int rc;
+    // global read table: bin, length, region; job counts per bin
+    struct RInfo { uint64_t off; uint32_t len, region; uint8_t bin; };
+    std::vector<RInfo> rinfo(nr);
+    std::vector<RegionRef> rtab_regions(n_regions);
+    std::vector<SeqRef> haps(nh);
+    uint64_t count[kBins] = {0};
+    uint32_t max_h = 0;
+    {
+        uint64_t r_at = 0, h_at = 0, rb = 0, hb = 0;
+        for (uint32_t g = 0; g < n_regions; ++g) {
+            const mgx_pairhmm_input_t& in = regs[g];
+            RegionRef& R = rtab_regions[g];
+            R.hap_begin = (uint32_t)h_at; R.n_haps = (uint32_t)in.n_haps; R.read_base = (uint32_t)r_at; R.out_base = (uint32_t)(*out_base)[g];
+            for (uint64_t h = 0; h < in.n_haps; ++h) {
+                const uint64_t H = in.hap_off[h + 1] - in.hap_off[h];
+                if (H == 0) { set_error("region %u: haplotype %llu is empty", g, (unsigned long long)h); return -EINVAL; }
+                if (H > 0x7FFFFFF0ull) { set_error("haplotype too long"); return -E2BIG; }
+                haps[h_at + h] = SeqRef{hb + (in.hap_off[h] - in.hap_off[0]), (uint32_t)H, (uint32_t)h};
+                max_h = std::max<uint32_t>(max_h, (uint32_t)H);
+            }
+            std::stable_sort(haps.begin() + h_at, haps.begin() + h_at + in.n_haps, [](const SeqRef& a, const SeqRef& b2) { return a.len < b2.len; });
+            for (uint64_t r = 0; r < in.n_reads; ++r) {
+                const uint64_t Rl = in.read_off[r + 1] - in.read_off[r];
+                if (Rl == 0) { set_error("region %u: read %llu is empty", g, (unsigned long long)r); return -EINVAL; }
+                int G, RPL;
+                shape_of((uint32_t)std::min<uint64_t>(Rl, 0xFFFFFFFFull), &G, &RPL);
+                if (G == 0) { set_error("region %u: read of %llu bases exceeds the %d-row limit", g, (unsigned long long)Rl, kMaxRowsG64); return -E2BIG; }
+                RInfo& ri = rinfo[r_at + r];
+                ri.off = rb + (in.read_off[r] - in.read_off[0]); ri.len = (uint32_t)Rl; ri.region = g; ri.bin = (uint8_t)bin_index(G, RPL);
+                count[ri.bin] += in.n_haps;
+            }
+            if (in.n_reads) rb += in.read_off[in.n_reads] - in.read_off[0];
+            if (in.n_haps) hb += in.hap_off[in.n_haps] - in.hap_off[0];
+            r_at += in.n_reads; h_at += in.n_haps;
+        }
+    }
+    int remap[kBins];
+    merge_small_bins(count, remap);
+    uint64_t reads_in[kBins] = {0}, rstart[kBins + 1] = {0}, jobs_in[kBins] = {0}, cells_in[kBins] = {0}, bytes_in[kBins] = {0};
+    std::vector<uint64_t> sumH(n_regions, 0);
+    for (uint32_t g = 0; g < n_regions; ++g)
+        for (uint32_t h = 0; h < rtab_regions[g].n_haps; ++h) sumH[g] += haps[rtab_regions[g].hap_begin + h].len;
+    for (uint64_t r = 0; r < nr; ++r) {
+        RInfo& ri = rinfo[r];
+        ri.bin = (uint8_t)remap[ri.bin];
+        const RegionRef& R = rtab_regions[ri.region];
+        reads_in[ri.bin]++; jobs_in[ri.bin] += R.n_haps; cells_in[ri.bin] += (uint64_t)ri.len * sumH[ri.region];
+        bytes_in[ri.bin] += 5ull * ri.len * R.n_haps + sumH[ri.region] + 4ull * R.n_haps;
+    }
+    for (int k = 0; k < kBins; ++k) rstart[k + 1] = rstart[k] + reads_in[k];
+    // slab layout
+    size_t off = 0;
+    const size_t o_rtab = off;  off = align_up(off + nr * sizeof(SeqRef));
+    const size_t o_rreg = off;  off = align_up(off + nr * sizeof(uint32_t));
+    const size_t o_rpre = off;  off = align_up(off + (nr + 1) * sizeof(uint32_t));
+    const size_t o_gtab = off;  off = align_up(off + n_regions * sizeof(RegionRef));
+    const size_t o_htab = off;  off = align_up(off + nh * sizeof(SeqRef));
+    const size_t o_bases = off; off = align_up(off + read_bytes);
+    const size_t o_qual = off;  off = align_up(off + read_bytes);
+    const size_t o_ins = off;   off = align_up(off + read_bytes);
+    const size_t o_del = off;   off = align_up(off + read_bytes);
+    const size_t o_gcp = off;   off = align_up(off + read_bytes);
+    const size_t o_hap = off;   off = align_up(off + hap_bytes);
+    b->in_bytes = off;
+    const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
+    b->o_out = off;             off = align_up(off + n * sizeof(double));
+    b->o_used = off;            off = align_up(off + n);
+    b->o_keep = off;
+    b->result_bytes = off - b->o_out;
+    const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
+    const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
+    if ((rc = acquire_slab(c, off, true, &b->slab))) return rc;
+    uint8_t* dv = b->slab.dev; uint8_t* pin = b->slab.pin;
+    b->d_jobs = (Job*)(dv + o_jobs);
+    b->d_bases = dv + o_bases; b->d_qual = dv + o_qual; b->d_ins = dv + o_ins; b->d_del = dv + o_del;
+    b->d_gcp = dv + o_gcp; b->d_hap = dv + o_hap;
+    b->d_out = (double*)(dv + b->o_out); b->d_used = dv + b->o_used;
+    b->d_rerun_list = (uint32_t*)(dv + o_rlist); b->d_rerun_count = (uint32_t*)(dv + o_rcount);
+    SeqRef* rtab = (SeqRef*)(pin + o_rtab);
+    uint32_t* rreg = (uint32_t*)(pin + o_rreg);
+    uint32_t* rpre = (uint32_t*)(pin + o_rpre);
+    {
+        uint64_t cur[kBins];
+        for (int k = 0; k < kBins; ++k) cur[k] = rstart[k];
+        for (uint64_t r = 0; r < nr; ++r) {
+            const RInfo& ri = rinfo[r];
+            const uint64_t at = cur[ri.bin]++;
+            rtab[at] = SeqRef{ri.off, ri.len, (uint32_t)r};
+            rreg[at] = ri.region;
+        }
+        uint32_t run = 0;
+        for (uint64_t at = 0; at < nr; ++at) { rpre[at] = run; run += rtab_regions[rreg[at]].n_haps; }
+        rpre[nr] = run;
+    }
+    memcpy(pin + o_gtab, rtab_regions.data(), n_regions * sizeof(RegionRef));
+    memcpy(pin + o_htab, haps.data(), nh * sizeof(SeqRef));
+    {
+        size_t rb = 0, hb = 0;
+        for (uint32_t g = 0; g < n_regions; ++g) {
+            const mgx_pairhmm_input_t& in = regs[g];
+            if (in.n_reads) {
+                const uint64_t o0 = in.read_off[0], len = in.read_off[in.n_reads] - o0;
+                memcpy(pin + o_bases + rb, in.bases + o0, len); memcpy(pin + o_qual + rb, in.qual + o0, len);
+                memcpy(pin + o_ins + rb, in.ins + o0, len);     memcpy(pin + o_del + rb, in.del + o0, len);
+                memcpy(pin + o_gcp + rb, in.gcp + o0, len);
+                rb += len;
+            }
+            if (in.n_haps) {
+                const uint64_t o0 = in.hap_off[0], len = in.hap_off[in.n_haps] - o0;
+                memcpy(pin + o_hap + hb, in.hap_bases + o0, len);
+                hb += len;
+            }
+        }
+    }
+    hipStream_t s = c->copy;
+    HIP_TRY(hipMemcpyAsync(dv, pin, b->in_bytes, hipMemcpyHostToDevice, s));
+    uint64_t job_begin = 0;
+    for (int k = 0; k < kBins; ++k) {
+        if (!reads_in[k]) continue;
+        Bin bin;
+        bin_shape(k, &bin);
+        bin.job_begin = (uint32_t)job_begin;
+        bin.job_count = (uint32_t)jobs_in[k];
+        bin.max_h = max_h;
+        bin.cells = cells_in[k];
+        bin.alg_bytes = bytes_in[k];
+        if ((rc = finalize_bin(bin, c->n_cu))) return rc;
+        b->stats.cells += bin.cells; b->stats.alg_bytes += bin.alg_bytes;
+        b->bins.push_back(bin);
+        job_begin += bin.job_count;
+    }
+    // one enumeration launch for all bins: jobs are laid out in read-table order, which is bin order
+    hipLaunchKernelGGL(pairhmm_make_jobs_multi, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const SeqRef*)(dv + o_rtab),
+                       (const uint32_t*)(dv + o_rreg), (const uint32_t*)(dv + o_rpre), (uint32_t)nr, (const RegionRef*)(dv + o_gtab),
+                       (const SeqRef*)(dv + o_htab), (uint32_t)n, b->d_jobs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->uploaded, s));
+    return 0;
+}
+
 }  // namespace
 
 int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
@@ -765,6 +926,36 @@ int mgx_pairhmm_compute(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, double*
     if (!rc) rc = mgx_pairhmm_batch_results(c, b, out_log10, nullptr);
     mgx_pairhmm_batch_destroy(c, b);
     return rc;
+}
+
+int mgx_pairhmm_compute_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_input_t* regions, double* const* out_log10) {
+    if (!c || (n_regions && (!regions || !out_log10))) { set_error("NULL argument"); return -EINVAL; }
+    if (n_regions == 0) return 0;
+    int rc;
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        if ((rc = validate(&regions[g]))) return rc;
+        if (regions[g].n_reads * regions[g].n_haps && !out_log10[g]) { set_error("region %u: output pointer is NULL", g); return -EINVAL; }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
+        new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+    if (!b) return -ENOMEM;
+    std::vector<uint64_t> base;
+    if ((rc = create_cross_multi(c, n_regions, regions, b.get(), &base))) return rc;
+    if (b->n_pairs == 0) return 0;
+    if (c->flags & MGX_PAIRHMM_TIMING) {
+        b->ev.resize(b->bins.size() * 4);
+        for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    mgx_pairhmm_batch_t* raw = b.release();
+    rc = mgx_pairhmm_batch_run(c, raw);
+    std::vector<double> all;
+    if (!rc) { all.resize(raw->n_pairs); rc = mgx_pairhmm_batch_results(c, raw, all.data(), nullptr); }
+    mgx_pairhmm_batch_destroy(c, raw);
+    if (rc) return rc;
+    for (uint32_t g = 0; g < n_regions; ++g)
+        if (base[g + 1] > base[g]) memcpy(out_log10[g], all.data() + base[g], (base[g + 1] - base[g]) * sizeof(double));
+    return 0;
 }
 
 }  // extern "C"

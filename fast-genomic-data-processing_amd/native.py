@@ -44,6 +44,7 @@ PAIRHMM_SYMBOLS = {
     "mgx_pairhmm_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
     "mgx_pairhmm_destroy": (None, [C.c_void_p]),
     "mgx_pairhmm_compute": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_void_p]),
+    "mgx_pairhmm_compute_regions": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_batch_create": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.POINTER(C.c_void_p)]),
     "mgx_pairhmm_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_batch_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -96,6 +96,22 @@ class PairHMMEngine:
         native.check(self.lib.mgx_pairhmm_compute(self.ctx, C.byref(inp), _ptr(out)))
         return out
 
+    def compute_regions(self, regions):
+        """Row F1: several active regions (dicts in the cross-product form) in ONE device batch.
+        Returns one [n_reads][n_haps] array per region."""
+        n = len(regions)
+        arr = (native.PairHMMInput * n)()
+        keeps, outs = [], []
+        ptrs = (C.c_void_p * n)()
+        for g, d in enumerate(regions):
+            d = dict(d); d["pair_read"] = None; d["pair_hap"] = None
+            inp, keep = make_input(d)
+            arr[g] = inp; keeps.append(keep)
+            o = np.empty((int(inp.n_reads), int(inp.n_haps)), dtype=np.float64)
+            outs.append(o); ptrs[g] = o.ctypes.data
+        native.check(self.lib.mgx_pairhmm_compute_regions(self.ctx, n, C.cast(arr, C.c_void_p), C.cast(ptrs, C.c_void_p)))
+        return outs
+
     def region(self, d, mapq, **model_overrides):
         """computeReadLikelihoods for one sample on the device: raw qualities in, normalised
         [n_reads][n_haps] log10 likelihoods and the keep mask of filterPoorlyModeledEvidence out."""

@@ -11,6 +11,7 @@
  *                                    intel/pairhmm/IntelPairHmm.h:39, IntelPairHmm.cc:259-293
  *                                    and computeLikelihoodsNative_concurrent_i  (:332-351), the
  *                                    per-test-case loop of VectorLoglessPairHMM.cpp:118-119
+ *   mgx_pairhmm_compute_regions   <- that call for several active regions at once (row F1)
  *   mgx_pairhmm_batch_*           <- the same call split into upload / run / download so a caller
  *                                    can keep several active regions in flight (replaces the
  *                                    tail-phase work sharing, IntelPairHmm.cc:296-330, 659-693)
@@ -100,6 +101,14 @@ void mgx_pairhmm_destroy(mgx_pairhmm_t* ctx);
 
 /* One shot: host buffers in, log10 likelihoods out (out_log10[i] for test case i). */
 int mgx_pairhmm_compute(mgx_pairhmm_t* ctx, const mgx_pairhmm_input_t* in, double* out_log10);
+
+/* several active regions in ONE device batch (one upload, one set of launches,
+ * one download) -- what replaces the reference's tail-phase work sharing between worker threads
+ * (main.cpp:302-315, IntelPairHmm.cc:296-330).  Every region is given in the cross-product form
+ * (pair arrays NULL); out_log10[g] receives region g's [n_reads][n_haps] block.  Values are identical
+ * to one mgx_pairhmm_compute call per region (a test case's result does not depend on its batch). */
+int mgx_pairhmm_compute_regions(mgx_pairhmm_t* ctx, uint32_t n_regions, const mgx_pairhmm_input_t* regions,
+                                double* const* out_log10);
 
 /* Staged form.  batch_create bins the test cases by shape, stages the packed arrays through
  * pinned memory and uploads them on the context's copy stream; after it returns the batch is

@@ -66,7 +66,22 @@ int main(int argc, char** argv) {
     hmm.initialize(haps, per_sample, 0, 0);
     MockMatrix m; m.n_reads = n_reads; m.v.assign((size_t)n_haps * n_reads, 0.0);
     for (int h = n_haps - 1; h >= 0; --h) m.order.push_back(haps[h]);      // reversed allele order on purpose
-    hmm.computeLog10Likelihoods(&m, reads, &gcp);
+    if (argc > 2 && std::string(argv[2]) == "queue") {
+        // row F1: the same reads as three "regions" (same haplotypes) parked and sent as one batch
+        std::vector<std::vector<std::shared_ptr<MockRead>>> parts(3);
+        for (int r = 0; r < n_reads; ++r) parts[r % 3].push_back(reads[r]);
+        std::vector<MockMatrix> ms(3);
+        for (int k = 0; k < 3; ++k) {
+            ms[k].n_reads = (int)parts[k].size(); ms[k].v.assign((size_t)n_haps * parts[k].size(), 0.0); ms[k].order = m.order;
+            hmm.enqueue(&ms[k], parts[k], &gcp);
+        }
+        if (hmm.queued() != 3) return 3;
+        hmm.flush();
+        for (int r = 0; r < n_reads; ++r)
+            for (int a = 0; a < n_haps; ++a) m.v[(size_t)a * n_reads + r] = ms[r % 3].v[(size_t)a * ms[r % 3].n_reads + r / 3];
+    } else {
+        hmm.computeLog10Likelihoods(&m, reads, &gcp);
+    }
     for (int a = 0; a < n_haps; ++a) { for (int r = 0; r < n_reads; ++r) printf("%.17g ", m.v[(size_t)a * n_reads + r]); printf("\n"); }
     return 0;
 }

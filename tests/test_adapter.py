@@ -51,6 +51,10 @@ def test_adapter_matches_oracle(tmp_path, oracle, synth):
     want = want[::-1]                               # the mock matrix lists alleles in reverse order
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 1e-5
+    # row F1: the same reads parked as three regions and flushed as ONE device batch: identical values
+    out_q = subprocess.check_output([build_adapter(), str(path), "queue"], text=True)
+    got_q = np.array([[float(x) for x in line.split()] for line in out_q.strip().splitlines()])
+    assert np.array_equal(got_q, got)
     # duplicated reads must come out bit-identical (they are computed once)
     for k in range(6):
         src, dst = k % (n_reads - 6), n_reads - 6 + k

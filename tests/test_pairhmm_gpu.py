@@ -204,3 +204,23 @@ def test_batches_in_flight(engine, oracle, synth):
         want, _ = oracle.batch(d)
         assert_log10_close(b.results(), want)
         b.close()
+
+
+def test_many_regions_in_one_batch(engine, synth):
+    """Row F1: coalescing active regions into one device batch returns, bit for bit, what one call per
+    region returns (regions of different sizes and read-length classes, one of them a single pair)."""
+    shapes = [(24, 16, (20, 128), (64, 256)), (1, 1, (100, 100), (200, 200)), (40, 25, (90, 151), (150, 400)),
+              (7, 3, (200, 400), (300, 600)), (60, 9, (30, 60), (40, 90)), (3, 40, (151, 151), (200, 300))]
+    regions = [synth.gen_pairhmm_region(nr, nh, 100 + k, r_range=rr, h_range=hr) for k, (nr, nh, rr, hr) in enumerate(shapes)]
+    got = engine.compute_regions(regions)
+    for d, o in zip(regions, got):
+        dd = dict(d); dd["pair_read"] = None; dd["pair_hap"] = None
+        want = engine.compute(dd).reshape(o.shape)
+        assert np.array_equal(o, want)
+    # sub-views: a region whose offset tables do not start at zero
+    d = regions[2]
+    ro, ho = np.asarray(d["read_off"]), np.asarray(d["hap_off"])
+    sub = dict(d); sub["read_off"] = ro[5:21]; sub["hap_off"] = ho[3:12]
+    full = got[2]
+    part = engine.compute_regions([sub])[0]
+    assert np.array_equal(part, full[5:20, 3:11])
