@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, c
 
 template <bool DOUBLE, bool PK>
 __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, const u64* __restrict__ k2,
-                                                   const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
+                                                   const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs, u32 n_records,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
                                                    uint8_t* __restrict__ dup, const u32* __restrict__ multi_list, const u32* n_multi,
                                                    u32* __restrict__ long_list, u32* n_long) {
@@ -689,7 +689,13 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
         const mgx_rec_t ra = recs[r0], rb = recs[r1];
         u64 q0, q1;
         if (DOUBLE) {
-            const uint16_t ma = recs[ra.mate].score, mb = recs[rb.mate].score;
+            // mates sit next to each other in arrival order (mgx_sortdedup_pack emits record 1, record 2):
+            // the neighbour in the same 64-byte pair is fetched together with the record instead of
+            // after it; only a mate that lives elsewhere costs a second, dependent gather
+            const u32 na = r0 ^ 1u, nb = r1 ^ 1u;
+            uint16_t ma = na < n_records ? recs[na].score : (uint16_t)0, mb = nb < n_records ? recs[nb].score : (uint16_t)0;
+            if (ra.mate != na) ma = recs[ra.mate].score;
+            if (rb.mate != nb) mb = recs[rb.mate].score;
             q0 = quality_word((uint16_t)(ra.score + ma), ra);                 // pair.cpp:81: uint16 sum
             q1 = quality_word((uint16_t)(rb.score + mb), rb);
         } else {
@@ -936,7 +942,7 @@ void launch_mark(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, 
     const u32 per = 256 * kFindItems;
     hipLaunchKernelGGL((k_find_runs<DOUBLE, PK>), dim3((n_entries + per - 1) / per), dim3(256), 0, s, k1, k2, rec, n_entries,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi);
-    hipLaunchKernelGGL((k_mark_list<DOUBLE, PK>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
+    hipLaunchKernelGGL((k_mark_list<DOUBLE, PK>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs, c->n,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, q.longl, n_long);
     hipLaunchKernelGGL((k_mark_long<DOUBLE, PK>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.longl, n_long);
