@@ -180,7 +180,13 @@ def smithwaterman_leg(pkg, synth, args, rank, local_rank):
            "value": st["cells"] / (ms_fill + ms_trace) / 1e6, "unit": "GCUPS", "dtype": "i32",
            "config": {"workload": "synthetic reads (100-151 bases) against haplotype windows (250-400 bases), STANDARD_NGS "
                                   "parameters, SOFTCLIP", "pairs": n, "cells": st["cells"]},
-           "ms_fill": ms_fill, "ms_trace": ms_trace, "backtrace_bytes": st["backtrace_bytes"]}
+           "ms_fill": ms_fill, "ms_trace": ms_trace, "backtrace_bytes": st["backtrace_bytes"],
+           "roofline": {"bound": "hbm", "achieved": st["cells"] / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": st["cells"] / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "k_sw_fill<8>", "kernel_ms": ms_fill,
+                        "note": "1 algorithmic byte per cell (the back-trace byte); the fill is int32-VALU bound (about 22 "
+                                "instructions per cell, 64 % of the lanes and 76 % of the anti-diagonal steps busy at this shape), "
+                                "the trace is a latency chain"}}
     if not args.no_cpu_baseline:
         so = os.path.join(ROOT, "oracle", "_ref", "libref_smithwaterman.so")
         if os.path.exists(so):
