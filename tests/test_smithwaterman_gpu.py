@@ -20,7 +20,8 @@ def test_golden_vectors(sw_engine):
 
 @pytest.mark.parametrize("ref_range,alt_range,n", [((1, 64), (1, 64), 1500), ((60, 130), (20, 150), 800),
                                                    ((250, 520), (100, 300), 300), ((900, 1100), (50, 400), 60),
-                                                   ((1500, 2048), (100, 300), 20)])
+                                                   ((1500, 2048), (100, 300), 20),
+                                                   ((1900, 2048), (4000, 8000), 3)])      # long alternates
 def test_random_vs_oracle(sw_engine, sw_oracle, synth, ref_range, alt_range, n):
     """every row class of the fill kernel (1, 2, 4, 8, 16, 32 rows per lane), all strategies"""
     for seed, params in ((11, (25, -50, -110, -6)), (12, (3, -1, -4, -3))):
