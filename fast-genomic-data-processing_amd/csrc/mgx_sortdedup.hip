@@ -75,8 +75,15 @@ struct Scalars {
 // few hundred bases).  14 delta bits + 2 orientation bits + a 32-bit position = 48 key bits: six
 // 8-bit passes (a 16-bit delta would cost a seventh).
 constexpr int kNearDeltaBits = 14;
-constexpr int kNearShift = kNearDeltaBits + 2;
 constexpr u64 kNearSpan = 1ull << kNearDeltaBits;
+// The identity occupies the upper 48 bits of the key word and only those are sorted; the 16 bits
+// below ride along for free and carry 0xFFFF - (pair score), so the duplicate search knows the better
+// pair of a run from the sorted keys alone and gathers records only for the losers' mate index (and
+// on the rare score tie).
+constexpr int kNearScoreBits = 16;
+constexpr int kNearDeltaShift = kNearScoreBits;                       // delta
+constexpr int kNearOrientShift = kNearScoreBits + kNearDeltaBits;     // orientation
+constexpr int kNearShift = kNearOrientShift + 2;                      // record 1's 5' end
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
@@ -113,7 +120,7 @@ struct BuildOut {
     u64 L;
     int packed_coord;                     // ckey = coord << 32 | i (every coordinate < 2^32)
     int packed_pair;                      // dk2 = mate 5' end << 32 | record (every 5' end < 2^32)
-    u64* nk; u32* nrec;                   // near double pairs: one key word p1 << 16 | orient << 14 | (p2 - p1)
+    u64* nk; u32* nrec;                   // near double pairs: one key word p1 << 32 | orient << 30 | (p2 - p1) << 16 | inverted pair score
     int near_enabled;
 };
 
@@ -141,10 +148,10 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
         const u32 i = base + k * 256 + threadIdx.x;
-        coord[k] = 0; p5[k] = 0; mate[k] = MGX_NO_MATE; flag[k] = kIgnorable;
-        if (i < n) { coord[k] = recs[i].coord; p5[k] = recs[i].prime5; mate[k] = recs[i].mate; flag[k] = recs[i].flag; }
+        coord[k] = 0; p5[k] = 0; mate[k] = MGX_NO_MATE; flag[k] = kIgnorable;      // flag: SAM flag | score << 16
+        if (i < n) { coord[k] = recs[i].coord; p5[k] = recs[i].prime5; mate[k] = recs[i].mate; flag[k] = (u32)recs[i].flag | (u32)recs[i].score << 16; }
     }
-    u64 mp5[ITEMS]; u32 mflag[ITEMS];
+    u64 mp5[ITEMS]; u32 mflag[ITEMS];      // mflag: mate's flag | mate's score << 16
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
         if (i < n && mate[k] != MGX_NO_MATE && mate[k] >= n) { bad = true; mate[k] = MGX_NO_MATE; flag[k] |= kIgnorable; }
         mp5[k] = 0; mflag[k] = 0;
         // only record 1 of a pair (mate > i, not ignorable) looks at its mate
-        if (i < n && !(flag[k] & kIgnorable) && mate[k] != MGX_NO_MATE && mate[k] > i) { mp5[k] = recs[mate[k]].prime5; mflag[k] = recs[mate[k]].flag; }
+        if (i < n && !(flag[k] & kIgnorable) && mate[k] != MGX_NO_MATE && mate[k] > i) { mp5[k] = recs[mate[k]].prime5; mflag[k] = (u32)recs[mate[k]].flag | (u32)recs[mate[k]].score << 16; }
     }
     if (bad) sc->bad_mate = 1;
 
@@ -181,7 +188,9 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
                 m_k1d = max(m_k1d, k1); m_k2d = max(m_k2d, p2);
                 // near pair: the whole (sort_key, mate end) identity fits one word, injectively
                 const bool near = o.near_enabled && p2 - p1 < kNearSpan;
-                const u64 nkey = (p1 << kNearShift) | ((u64)orient << kNearDeltaBits) | (p2 - p1);
+                const u32 pair_score = ((flag[k] >> 16) + (mflag[k] >> 16)) & 0xFFFFu;              // pair.cpp:81: uint16 sum
+                const u64 nkey = (p1 << kNearShift) | ((u64)orient << kNearOrientShift) | ((p2 - p1) << kNearDeltaShift) |
+                                 (u64)(0xFFFFu - pair_score);
                 c = near ? 3 : 1;
                 wa = near ? nkey : k1;
                 wb = p2;
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(256) void k_indicator_tiles(const u64* __restrict__
     }
 }
 
-// Near pairs (one key word p1 << 16 | orient << 14 | delta, sorted): both ends of every pair in ONE
+// Near pairs (one key word p1 << 32 | orient << 30 | delta << 16 | inverted score, sorted on its upper 48 bits): both ends of every pair in ONE
 // pass.  A pair's record-1 end lies in the tile of p1, its record-2 end at p1 + delta < p1 + kNearSpan in
 // that tile or the next, so tile t scans the entries with p1 in [t*65536 - (kNearSpan - 1), (t+1)*65536).
 // Always the first pass over the bitmap: defines every word.
@@ -559,8 +568,8 @@ __global__ __launch_bounds__(256) void k_indicator_tiles_near(const u64* __restr
     const u32 lo = s_lo, hi = s_hi;
     for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
         const u64 key = nk[i];
-        const u64 p1 = key >> kNearShift, p2 = p1 + (key & (kNearSpan - 1));
-        const u32 orient = (u32)(key >> kNearDeltaBits) & 3u;
+        const u64 p1 = key >> kNearShift, p2 = p1 + ((key >> kNearDeltaShift) & (kNearSpan - 1));
+        const u32 orient = (u32)(key >> kNearOrientShift) & 3u;
         if (p1 >= pos_lo) {                                  // record 1 forward: FF, FR
             const u32 p = (u32)(p1 - pos_lo);
             atomicOr((orient == 0u || orient == 1u) ? &fw[p >> 5] : &rv[p >> 5], 1u << (p & 31));
@@ -582,8 +591,8 @@ __global__ __launch_bounds__(256) void k_set_indicator_near(const u64* __restric
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const u64 key = nk[i];
-    const u64 p1 = key >> kNearShift, p2 = p1 + (key & (kNearSpan - 1));
-    const u32 orient = (u32)(key >> kNearDeltaBits) & 3u;
+    const u64 p1 = key >> kNearShift, p2 = p1 + ((key >> kNearDeltaShift) & (kNearSpan - 1));
+    const u32 orient = (u32)(key >> kNearOrientShift) & 3u;
     const u64 b1 = p1 + ((orient == 0u || orient == 1u) ? 0ull : L), b2 = p2 + ((orient == 0u || orient == 2u) ? 0ull : L);
     if (b1 < indicator_bits) atomicOr(&indicator[b1 >> 5], 1u << (b1 & 31));
     if (b2 < indicator_bits) atomicOr(&indicator[b2 >> 5], 1u << (b2 & 31));
@@ -619,7 +628,7 @@ __device__ __forceinline__ u64 quality_single(const mgx_rec_t* recs, u32 rec) {
 // PK: the second array holds (mate 5' end << 32 | record) packed in one word and `rec` is unused.
 constexpr int kFindItems = 16;
 
-template <bool DOUBLE, bool PK>
+template <bool DOUBLE, bool PK, int KS>
 __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, const u64* __restrict__ k2,
                                                    const u32* __restrict__ rec, u32 n,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
@@ -640,11 +649,11 @@ __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, c
         bool multi = false;
         // neighbours come from the adjacent lanes; only the two edge lanes of a wavefront load theirs
         const int lane = threadIdx.x & 63;
-        const u64 a1 = i < n ? k1[i] : 0ull, a2 = i < n ? K2(i) : 0ull;
+        const u64 a1 = i < n ? k1[i] >> KS : 0ull, a2 = i < n ? K2(i) : 0ull;     // KS: key bits below the identity
         u64 p1 = __shfl_up(a1, 1, 64), p2 = DOUBLE ? __shfl_up(a2, 1, 64) : 0ull;
         u64 n1 = __shfl_down(a1, 1, 64), n2 = DOUBLE ? __shfl_down(a2, 1, 64) : 0ull;
-        if (lane == 0 && i > 0 && i < n) { p1 = k1[i - 1]; p2 = K2(i - 1); }
-        if (lane == 63 && i + 1 < n) { n1 = k1[i + 1]; n2 = K2(i + 1); }
+        if (lane == 0 && i > 0 && i < n) { p1 = k1[i - 1] >> KS; p2 = K2(i - 1); }
+        if (lane == 63 && i + 1 < n) { n1 = k1[i + 1] >> KS; n2 = K2(i + 1); }
         if (i < n) {
             const bool head = i == 0 || p1 != a1 || (DOUBLE && p2 != a2);
             if (head) {
@@ -671,7 +680,7 @@ __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, c
         if ((is_multi >> k) & 1u) multi_list[s_base + slot[k]] = base + k * 256 + threadIdx.x;
 }
 
-template <bool DOUBLE, bool PK>
+template <bool DOUBLE, bool PK, int KS>
 __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, const u64* __restrict__ k2,
                                                    const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs, u32 n_records,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
@@ -682,6 +691,43 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
     const u32 total = *n_multi;
     for (u32 li = blockIdx.x * 256 + threadIdx.x; li < total; li += gridDim.x * 256) {
         const u32 i = multi_list[li];
+        if constexpr (KS > 0) {
+            // near pairs: the low KS bits of the key word are 0xFFFF - pair score, so the best entry of
+            // the run is known from the sorted keys; records are gathered only when several entries
+            // share the best score (tile, x, y, then arrival order decide) and for the losers' mates
+            const u64 id = k1[i] >> KS;
+            u32 best = i, bs = (u32)(k1[i] & ((1u << KS) - 1));
+            bool tie = false;
+            u32 j = i + 1;
+            for (; j < n && j - i < kWalkCap; ++j) {
+                const u64 kj = k1[j];
+                if ((kj >> KS) != id) break;
+                const u32 sj = (u32)(kj & ((1u << KS) - 1));
+                if (sj < bs) { bs = sj; best = j; tie = false; }
+                else if (sj == bs) tie = true;
+            }
+            if (j < n && j - i >= kWalkCap && (k1[j] >> KS) == id) {
+                long_list[atomicAdd(n_long, 1u)] = i;                                 // long run: defer
+                continue;
+            }
+            if (tie) {
+                u64 bq = ~0ull; u32 br = 0xFFFFFFFFu;
+                for (u32 t = i; t < j; ++t) {
+                    if ((u32)(k1[t] & ((1u << KS) - 1)) != bs) continue;
+                    const u32 rt = REC(t);
+                    const mgx_rec_t a = recs[rt];
+                    const u64 q = ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y;
+                    if (q < bq || (q == bq && rt < br)) { bq = q; br = rt; best = t; }
+                }
+            }
+            for (u32 t = i; t < j; ++t) {
+                if (t == best) continue;
+                const u32 r = REC(t);
+                dup[r] = 1;
+                dup[recs[r].mate] = 1;
+            }
+            continue;
+        }
         const u64 a1 = k1[i], a2 = K2(i);
         // the first two entries belong to the run by construction: their record gathers (the slow,
         // random part) are issued together instead of one after the other
@@ -728,7 +774,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
     }
 }
 
-template <bool DOUBLE, bool PK>
+template <bool DOUBLE, bool PK, int KS>
 __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, const u64* __restrict__ k2,
                                                    const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
@@ -741,13 +787,13 @@ __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, c
     auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
     for (u32 li = blockIdx.x; li < *n_long; li += gridDim.x) {
         const u32 i = long_list[li];
-        const u64 a1 = k1[i], a2 = K2(i);
+        const u64 a1 = k1[i] >> KS, a2 = K2(i);          // KS: key bits below the identity
         // pass 1: extent of the run and its best entry
         u64 bq = ~0ull; u32 bp = 0xFFFFFFFFu, bpr = 0xFFFFFFFFu;
         u32 end = n;
         for (u32 c = i; c < n; c += 256) {
             const u32 t = c + threadIdx.x;
-            const bool in = t < n && k1[t] == a1 && (!DOUBLE || K2(t) == a2);
+            const bool in = t < n && (k1[t] >> KS) == a1 && (!DOUBLE || K2(t) == a2);
             if (threadIdx.x == 0) s_end = n;
             __syncthreads();
             if (t < n && !in) atomicMin(&s_end, t);
@@ -935,16 +981,16 @@ int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q,
 }
 
 // duplicate search over one sorted entry array: run heads -> dense list -> marks (+ long runs)
-template <bool DOUBLE, bool PK>
+template <bool DOUBLE, bool PK, int KS = 0>
 void launch_mark(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, const u32* rec, u32 n_entries,
                  const mgx_sortdedup::Scratch& q, u32* n_multi, u32* n_long, u64 ind_bits, u64 ind_off) {
     if (!n_entries) return;
     const u32 per = 256 * kFindItems;
-    hipLaunchKernelGGL((k_find_runs<DOUBLE, PK>), dim3((n_entries + per - 1) / per), dim3(256), 0, s, k1, k2, rec, n_entries,
+    hipLaunchKernelGGL((k_find_runs<DOUBLE, PK, KS>), dim3((n_entries + per - 1) / per), dim3(256), 0, s, k1, k2, rec, n_entries,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi);
-    hipLaunchKernelGGL((k_mark_list<DOUBLE, PK>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs, c->n,
+    hipLaunchKernelGGL((k_mark_list<DOUBLE, PK, KS>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs, c->n,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, q.longl, n_long);
-    hipLaunchKernelGGL((k_mark_long<DOUBLE, PK>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
+    hipLaunchKernelGGL((k_mark_long<DOUBLE, PK, KS>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.longl, n_long);
 }
 
@@ -1137,7 +1183,8 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     hipStream_t sN = (multi && tiled) ? c->side[0] : s;   // the atomic (non-tiled) bitmap needs the memset first
     hipStream_t sR = multi ? c->side[1] : s;
     int ncur = 0;
-    if ((rc = radix_sort(c, sN, c->scr[1], c->d_nk, nullptr, c->d_nrec, nn, 0, bits_of(c->sc.max_near), &ncur))) return rc;
+    if ((rc = radix_sort(c, sN, c->scr[1], c->d_nk, nullptr, c->d_nrec, nn, kNearScoreBits,
+                         std::max(bits_of(c->sc.max_near) - kNearScoreBits, 1), &ncur))) return rc;
     bool defined = false;                     // has a pass already written every word of the tiled bitmap?
     if (tiled && n && c->packed_pair) {
         hipLaunchKernelGGL(k_indicator_tiles_near, dim3(n_ind_tiles), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, Lp);
@@ -1146,7 +1193,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
     }
     HIP_TRY(hipEventRecord(c->ev_ind, sN));
-    launch_mark<true, false>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
+    launch_mark<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
     HIP_TRY(hipEventRecord(c->ev_side[0], sN));
 
     // records by unified coordinate (stable: equal coordinates keep arrival order)
