@@ -53,18 +53,27 @@ struct SwJob {
     u64 bt_off;          // back-trace arena, bytes
     u64 sc_off;          // score arena (int32): last_row[ncol + 1] then last_col[nrow + 1]
     u64 el_off;          // element arena (int16): 2 * (len1 + len2 + 2)
-    u32 len1, len2, rpl, strategy, out_index, pad_;
+    u32 len1, len2, rpl, strategy, out_index;
+    u32 g;               // lanes per pair (32 or 64)
 };
 
 struct SwResult { int32_t score, max_i, max_j, offset, n_elems; };
 struct SwParams { int match, mismatch, open, extend; };
 
-template <int RPL>
-__global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, const u8* __restrict__ s1, const u8* __restrict__ s2,
-                                                u8* __restrict__ bt, int32_t* __restrict__ sc, SwParams P) {
-    extern __shared__ u8 sh_b[];                      // the alternate sequence: one global load per step would
-    const SwJob J = jobs[blockIdx.x];                 // put ~200 serial HBM latencies on every wavefront's path
-    const int lane = threadIdx.x;
+// G lanes per pair (two pairs share a wavefront when G = 32), RPL rows per lane.  Back-trace byte:
+// bits 0-1 op, bit 2 INSERT_EXT, bit 3 DELETE_EXT (PairWiseSW.h:31-66).  (Storing the length of the
+// diagonal match run in the spare bits, so that the trace crosses a run in one step, was measured:
+// trace 0.58 -> 0.38 ms, fill 1.14 -> 1.42 ms per 20 000 pairs -- not kept.)
+template <int G, int RPL>
+__global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, u32 n_jobs, const u8* __restrict__ s1, const u8* __restrict__ s2,
+                                                u8* __restrict__ bt, int32_t* __restrict__ sc, u32 lds_stride, SwParams P) {
+    extern __shared__ u8 sh_all[];                    // the alternate sequences: one global load per step would
+    constexpr int GPW = 64 / G;                       // put ~200 serial HBM latencies on every wavefront's path
+    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+    const u32 job_idx = blockIdx.x * GPW + grp;
+    const bool live = job_idx < n_jobs;
+    SwJob J{};
+    if (live) J = jobs[job_idx];
     const int nrow = (int)J.len1, ncol = (int)J.len2;
     const bool indel = J.strategy == MGX_SW_INDEL || J.strategy == MGX_SW_LEADING_INDEL;
     const u8* a = s1 + J.off1;
@@ -72,25 +81,31 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
     int32_t* last_row = sc + J.sc_off;
     int32_t* last_col = last_row + ncol + 1;
     u8* btp = bt + J.bt_off;
-    for (int x = lane; x < ncol; x += 64) sh_b[x] = b[x];
+    u8* sh_b = sh_all + (size_t)grp * lds_stride;
+    for (int x = lane; x < ncol; x += G) sh_b[x] = b[x];
     __syncthreads();
     const int r0 = lane * RPL;                       // this lane owns rows r0+1 .. r0+RPL (1-based)
     int sa[RPL], hl[RPL], e[RPL];
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const int i = r0 + k + 1;
-        sa[k] = i <= nrow ? (int)a[i - 1] : 256;      // padding rows never match and feed nothing above them
+        sa[k] = (live && i <= nrow) ? (int)a[i - 1] : 256;        // padding rows never match and feed nothing above them
         hl[k] = indel ? P.open + (i - 1) * P.extend : 0;          // H(i, 0), PairWiseSW.h:243-253
         e[k] = kLowInit;                                          // E(i, 0)
     }
     int diag_in = r0 == 0 ? 0 : (indel ? P.open + (r0 - 1) * P.extend : 0);   // H(r0, 0)
-    const int n_lanes = (nrow + RPL - 1) / RPL;
-    const int steps = ncol + n_lanes - 1;
-    const int lane_last = (nrow - 1) / RPL, k_last = (nrow - 1) % RPL;
+    const int n_lanes = live ? (nrow + RPL - 1) / RPL : 0;
+    const int steps = live ? ncol + n_lanes - 1 : 0;
+    int steps_w = steps;                              // the wavefront walks to its longest pair
+    if constexpr (GPW > 1) {
+        const int other = __shfl_xor(steps, G, 64);
+        steps_w = other > steps ? other : steps;
+    }
+    const int lane_last = live ? (nrow - 1) / RPL : -1, k_last = live ? (nrow - 1) % RPL : 0;
     int send_h = 0, send_f = kLowInit;
-    for (int t = 1; t <= steps; ++t) {
+    for (int t = 1; t <= steps_w; ++t) {
         // what the lane above computed for this column one step ago: H(r0, j), F(r0, j)
-        const int rh = __shfl_up(send_h, 1, 64), rf = __shfl_up(send_f, 1, 64);
+        const int rh = __shfl_up(send_h, 1, G), rf = __shfl_up(send_f, 1, G);
         const int j = t - lane;
         if (j >= 1 && j <= ncol && lane < n_lanes) {
             int up_h, up_f, diag;
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
                 for (int k = 1; k < RPL; ++k) if (k == k_last) v = hl[k];
                 last_row[j] = v;
             }
-            u8* dst = btp + ((size_t)t * 64 + lane) * RPL;
+            u8* dst = btp + ((size_t)t * G + lane) * RPL;
             if constexpr (RPL == 1) dst[0] = (u8)packed[0];
             else if constexpr (RPL == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed[0];
             else {
@@ -140,11 +155,12 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
 
 // One lane per pair: best end cell, back-trace, merged element list (in the order getCIGAR holds it).
 __global__ __launch_bounds__(64) void k_sw_trace(const SwJob* __restrict__ jobs, u32 n, const u8* __restrict__ bt,
-                                                 const int32_t* __restrict__ sc, int16_t* __restrict__ elems_all, SwResult* __restrict__ res) {
+                                                 const int32_t* __restrict__ sc, int16_t* __restrict__ elems_all, SwResult* __restrict__ res,
+                                                 int16_t* __restrict__ compact, int n_compact) {
     const u32 p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n) return;
     const SwJob J = jobs[p];
-    const int nrow = (int)J.len1, ncol = (int)J.len2, strategy = (int)J.strategy, rpl = (int)J.rpl;
+    const int nrow = (int)J.len1, ncol = (int)J.len2, strategy = (int)J.strategy, rpl = (int)J.rpl, g = (int)J.g;
     const int32_t* last_row = sc + J.sc_off;
     const int32_t* last_col = last_row + ncol + 1;
     const u8* btp = bt + J.bt_off;
@@ -172,7 +188,7 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwJob* __restrict__ jobs,
     int state = 0;
     while (i > 0 && j > 0) {
         const int l = (i - 1) / rpl, k = (i - 1) - l * rpl;
-        const int btr = btp[((size_t)(j + l) * 64 + l) * rpl + k];
+        const int btr = btp[((size_t)(j + l) * g + l) * rpl + k];
         if (state == kInsertExt) { --j; el[2 * m - 1]++; state = btr & kInsertExt; }
         else if (state == kDeleteExt) { --i; el[2 * m - 1]++; state = btr & kDeleteExt; }
         else {
@@ -203,11 +219,40 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwJob* __restrict__ jobs,
     }
     SwResult r; r.score = best; r.max_i = mi; r.max_j = mj; r.offset = offset; r.n_elems = w + 1;
     res[J.out_index] = r;
+    // alignments have a handful of elements: those travel back in a fixed-size record per pair
+    int16_t* ce = compact + (size_t)J.out_index * 2 * n_compact;
+    for (int q = 0; q <= w && q < n_compact; ++q) { ce[2 * q] = el[2 * q]; ce[2 * q + 1] = el[2 * q + 1]; }
 }
 
-int rpl_for(int nrow) {
-    for (int r = 1; r <= 32; r *= 2) if (nrow <= 64 * r) return r;
-    return 0;
+// alignments with more than kCompactElems elements: their element lists are packed densely for one download
+struct GatherRef { u64 src, dst; u32 n; u32 pad_; };     // int16 offsets, n = number of int16 values
+__global__ __launch_bounds__(256) void k_sw_gather(const GatherRef* __restrict__ refs, u32 n_refs, const int16_t* __restrict__ el,
+                                                   int16_t* __restrict__ dense) {
+    for (u32 r = blockIdx.x; r < n_refs; r += gridDim.x) {
+        const GatherRef g = refs[r];
+        for (u32 x = threadIdx.x; x < g.n; x += 256) dense[g.dst + x] = el[g.src + x];
+    }
+}
+
+// lanes per pair and rows per lane: two pairs share a wavefront up to 512 reference bases
+struct Shape { int g, rpl; };
+// `paired`: batches large enough to fill the device twice over put two pairs on a wavefront (better lane
+// use, fewer diagonal fill/drain steps); smaller batches keep one pair per wavefront so that every SIMD
+// still has several wavefronts to hide the dependent integer chain of a step behind.
+Shape shape_for(int nrow, bool paired) {
+    if (paired) {
+        static const int cls32[] = {1, 2, 4, 8, 12, 16};
+        for (int r : cls32) if (nrow <= 32 * r) return Shape{32, r};
+    }
+    static const int cls64[] = {1, 2, 4, 8, 16, 32};
+    for (int r : cls64) if (nrow <= 64 * r) return Shape{64, r};
+    return Shape{0, 0};
+}
+constexpr u32 kPairedFrom = 65536;            // pairs in a chunk from which two share a wavefront
+constexpr int kCompactElems = 16;             // merged CIGAR elements copied back per pair without a second look
+inline u64 bt_bytes(u64 len1, u64 len2, const Shape& sh) {
+    const u64 n_lanes = (len1 + sh.rpl - 1) / sh.rpl, steps = len2 + n_lanes - 1;
+    return ((steps + 1) * sh.g * sh.rpl + 15) & ~15ull;
 }
 
 int itoa_len(int v) { const int neg = v < 0; if (neg) v = -v; int d = 0; while (v > 0) { v /= 10; ++d; } return d + neg; }
@@ -255,7 +300,8 @@ struct mgx_sw {
     DevBuf<u8> d_s1, d_s2, d_bt;
     DevBuf<SwJob> d_jobs;
     DevBuf<int32_t> d_sc;
-    DevBuf<int16_t> d_el;
+    DevBuf<int16_t> d_el, d_cel, d_dense;
+    DevBuf<GatherRef> d_gather;
     DevBuf<SwResult> d_res;
     mgx_sw_stats_t stats{};
 };
@@ -263,15 +309,20 @@ struct mgx_sw {
 namespace {
 constexpr u64 kArenaLimit = 12ull << 30;      // back-trace bytes per chunk of a batch (MGX_SW_ARENA_LIMIT overrides, for tests)
 
-template <int RPL>
+template <int G, int RPL>
 void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, u32 max_len2, SwParams P) {
-    hipLaunchKernelGGL((k_sw_fill<RPL>), dim3(n), dim3(64), (max_len2 + 15) & ~15u, c->stream, jobs, c->d_s1.p, c->d_s2.p, c->d_bt.p, c->d_sc.p, P);
+    constexpr u32 GPW = 64 / G;
+    const u32 stride = (max_len2 + 15) & ~15u;
+    hipLaunchKernelGGL((k_sw_fill<G, RPL>), dim3((n + GPW - 1) / GPW), dim3(64), GPW * stride, c->stream, jobs, n, c->d_s1.p, c->d_s2.p,
+                       c->d_bt.p, c->d_sc.p, stride, P);
 }
 
 // pairs [lo, hi) of the input, already validated
 int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in, u64 lo, u64 hi,
               int32_t* out_offset, char* out_cigar, u32 stride, int32_t* out_score, int cap_override) {
     const u32 n = (u32)(hi - lo);
+    bool paired = n >= kPairedFrom;
+    if (const char* e = getenv("MGX_SW_PAIRED")) paired = atoi(e) != 0;      // tests: force either shape family
     std::vector<SwJob> jobs(n);
     const u64 base1 = in->ref_off[lo], base2 = in->alt_off[lo];
     u64 bt = 0, scn = 0, eln = 0;
@@ -280,18 +331,19 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         SwJob& J = jobs[q];
         J.off1 = in->ref_off[p] - base1; J.off2 = in->alt_off[p] - base2;
         J.len1 = (u32)(in->ref_off[p + 1] - in->ref_off[p]); J.len2 = (u32)(in->alt_off[p + 1] - in->alt_off[p]);
-        J.rpl = (u32)rpl_for((int)J.len1); J.strategy = in->strategy[p]; J.out_index = q; J.pad_ = 0;
-        const u64 n_lanes = (J.len1 + J.rpl - 1) / J.rpl, steps = J.len2 + n_lanes - 1;
-        J.bt_off = bt; bt += ((steps + 1) * 64 * J.rpl + 15) & ~15ull;
+        const Shape sh = shape_for((int)J.len1, paired);
+        J.rpl = (u32)sh.rpl; J.g = (u32)sh.g; J.strategy = in->strategy[p]; J.out_index = q;
+        J.bt_off = bt; bt += bt_bytes(J.len1, J.len2, sh);
         J.sc_off = scn; scn += (u64)J.len1 + J.len2 + 2;
         J.el_off = eln; eln += 2 * ((u64)J.len1 + J.len2 + 2);
     }
     // one fill launch per row class: sort the job list by rpl (stable; results go back through out_index)
-    std::stable_sort(jobs.begin(), jobs.end(), [](const SwJob& a, const SwJob& b) { return a.rpl < b.rpl; });
+    std::stable_sort(jobs.begin(), jobs.end(), [](const SwJob& a, const SwJob& b) { return a.g * 64 + a.rpl < b.g * 64 + b.rpl; });
     const u64 n1 = in->ref_off[hi] - base1, n2 = in->alt_off[hi] - base2;
     int rc;
     if ((rc = c->d_s1.reserve(n1 + 16)) || (rc = c->d_s2.reserve(n2 + 16)) || (rc = c->d_bt.reserve(bt + 16)) || (rc = c->d_jobs.reserve(n)) ||
-        (rc = c->d_sc.reserve(scn)) || (rc = c->d_el.reserve(eln)) || (rc = c->d_res.reserve(n))) return rc;
+        (rc = c->d_sc.reserve(scn)) || (rc = c->d_el.reserve(eln)) || (rc = c->d_res.reserve(n)) ||
+        (rc = c->d_cel.reserve((size_t)n * 2 * kCompactElems))) return rc;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_s1.p, in->ref + base1, n1, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_s2.p, in->alt + base2, n2, hipMemcpyHostToDevice, s));
@@ -301,35 +353,73 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
     for (u32 a = 0; a < n;) {
         u32 b = a;
         u32 m2 = 0;
-        while (b < n && jobs[b].rpl == jobs[a].rpl) { m2 = std::max(m2, jobs[b].len2); ++b; }
+        while (b < n && jobs[b].rpl == jobs[a].rpl && jobs[b].g == jobs[a].g) { m2 = std::max(m2, jobs[b].len2); ++b; }
         const SwJob* dj = c->d_jobs.p + a;
-        switch (jobs[a].rpl) {
-            case 1: launch_fill<1>(c, dj, b - a, m2, P); break;
-            case 2: launch_fill<2>(c, dj, b - a, m2, P); break;
-            case 4: launch_fill<4>(c, dj, b - a, m2, P); break;
-            case 8: launch_fill<8>(c, dj, b - a, m2, P); break;
-            case 16: launch_fill<16>(c, dj, b - a, m2, P); break;
-            default: launch_fill<32>(c, dj, b - a, m2, P); break;
+        if (jobs[a].g == 32) {
+            switch (jobs[a].rpl) {
+                case 1: launch_fill<32, 1>(c, dj, b - a, m2, P); break;
+                case 2: launch_fill<32, 2>(c, dj, b - a, m2, P); break;
+                case 4: launch_fill<32, 4>(c, dj, b - a, m2, P); break;
+                case 8: launch_fill<32, 8>(c, dj, b - a, m2, P); break;
+                case 12: launch_fill<32, 12>(c, dj, b - a, m2, P); break;
+                default: launch_fill<32, 16>(c, dj, b - a, m2, P); break;
+            }
+        } else {
+            switch (jobs[a].rpl) {
+                case 1: launch_fill<64, 1>(c, dj, b - a, m2, P); break;
+                case 2: launch_fill<64, 2>(c, dj, b - a, m2, P); break;
+                case 4: launch_fill<64, 4>(c, dj, b - a, m2, P); break;
+                case 8: launch_fill<64, 8>(c, dj, b - a, m2, P); break;
+                case 16: launch_fill<64, 16>(c, dj, b - a, m2, P); break;
+                default: launch_fill<64, 32>(c, dj, b - a, m2, P); break;
+            }
         }
         c->stats.n_launches++;
         a = b;
     }
     HIP_TRY(hipEventRecord(c->ev[1], s));
-    hipLaunchKernelGGL(k_sw_trace, dim3((n + 63) / 64), dim3(64), 0, s, c->d_jobs.p, n, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p);
+    hipLaunchKernelGGL(k_sw_trace, dim3((n + 63) / 64), dim3(64), 0, s, c->d_jobs.p, n, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
+                       c->d_cel.p, kCompactElems);
     HIP_TRY(hipEventRecord(c->ev[2], s));
     HIP_TRY(hipGetLastError());
     std::vector<SwResult> res(n);
-    std::vector<int16_t> el(eln);
+    std::unique_ptr<int16_t[]> cel(new (std::nothrow) int16_t[(size_t)n * 2 * kCompactElems]);
+    if (!cel) return -ENOMEM;
     HIP_TRY(hipMemcpyAsync(res.data(), c->d_res.p, n * sizeof(SwResult), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(el.data(), c->d_el.p, eln * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cel.get(), c->d_cel.p, (size_t)n * 2 * kCompactElems * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    // alignments with more elements than the fixed record holds: one gather launch, one more download
+    std::vector<GatherRef> big_refs;
+    std::vector<u64> big_at(n, ~0ull);
+    {
+        u64 eo2 = 0, dense_n = 0;
+        for (u32 q = 0; q < n; ++q) {
+            const u64 p = lo + q;
+            if (res[q].n_elems > kCompactElems) {
+                big_at[q] = dense_n;
+                big_refs.push_back(GatherRef{eo2, dense_n, (u32)(2 * res[q].n_elems), 0});
+                dense_n += 2ull * res[q].n_elems;
+            }
+            eo2 += 2 * ((in->ref_off[p + 1] - in->ref_off[p]) + (in->alt_off[p + 1] - in->alt_off[p]) + 2);
+        }
+        if (!big_refs.empty()) {
+            if ((rc = c->d_gather.reserve(big_refs.size())) || (rc = c->d_dense.reserve(dense_n))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->d_gather.p, big_refs.data(), big_refs.size() * sizeof(GatherRef), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_sw_gather, dim3((u32)std::min<size_t>(big_refs.size(), 65535)), dim3(256), 0, s, c->d_gather.p,
+                               (u32)big_refs.size(), c->d_el.p, c->d_dense.p);
+        }
+        big_at.push_back(dense_n);
+    }
+    std::unique_ptr<int16_t[]> big(new (std::nothrow) int16_t[big_at.back() + 1]);
+    if (!big) return -ENOMEM;
+    if (!big_refs.empty()) {
+        HIP_TRY(hipMemcpyAsync(big.get(), c->d_dense.p, big_at.back() * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->stats.ms_fill += ms;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->stats.ms_trace += ms;
     c->stats.backtrace_bytes += bt;
-    // el_off was assigned in input order before the sort, so pair q's elements are found through a second
-    // pass over the same running sum
-    u64 eo = 0;
     for (u32 q = 0; q < n; ++q) {
         const u64 p = lo + q;
         const u32 l1 = (u32)(in->ref_off[p + 1] - in->ref_off[p]), l2 = (u32)(in->alt_off[p + 1] - in->alt_off[p]);
@@ -338,12 +428,13 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         if (out_score) out_score[p] = r.score;
         if (out_cigar) {
             char* dst = out_cigar + (size_t)p * stride;
-            memset(dst, 0, stride);
             const int cap = cap_override >= 0 ? cap_override
                                               : (int)std::min<u64>(2ull * std::max(l1, l2), (u64)stride - 1);   // IntelSmithWaterman.cpp:8
-            render(el.data() + eo, r.n_elems, dst, cap);
+            const int16_t* src = cel.get() + (size_t)q * 2 * kCompactElems;
+            if (r.n_elems > kCompactElems) src = big.get() + big_at[q];
+            const int len = render(src, r.n_elems, dst, cap);
+            dst[len] = 0;                             // cap <= stride - 1
         }
-        eo += 2 * ((u64)l1 + l2 + 2);
         c->stats.cells += (u64)l1 * l2;
     }
     return 0;
@@ -408,7 +499,7 @@ static int align_impl(mgx_sw_t* c, const mgx_sw_params_t* params, const mgx_sw_i
         u64 hi = lo, bt = 0;
         while (hi < in->n_pairs) {
             const u64 l1 = in->ref_off[hi + 1] - in->ref_off[hi], l2 = in->alt_off[hi + 1] - in->alt_off[hi];
-            const u64 r = (u64)rpl_for((int)l1), need = (l2 + (l1 + r - 1) / r + 1) * 64 * r + 16;
+            const u64 need = bt_bytes(l1, l2, shape_for((int)l1, false)) + 16;     // the one-pair shape is the larger of the two
             if (hi > lo && bt + need > limit) break;
             bt += need; ++hi;
         }

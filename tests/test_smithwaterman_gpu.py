@@ -33,6 +33,18 @@ def test_random_vs_oracle(sw_engine, sw_oracle, synth, ref_range, alt_range, n):
         assert got_c == want_c
 
 
+@pytest.mark.parametrize("paired", ["0", "1"])
+def test_both_shape_families(sw_engine, sw_oracle, synth, monkeypatch, paired):
+    """large batches put two pairs on a wavefront (32 lanes each), small ones keep 64 lanes per pair:
+    force each family over every row class"""
+    monkeypatch.setenv("MGX_SW_PAIRED", paired)
+    for k, (rr, n) in enumerate((((1, 70), 300), ((100, 520), 300), ((600, 2048), 24))):
+        w = synth.gen_sw_pairs(n, 200 + k, ref_range=rr, alt_range=(5, 260))
+        want_c, want_o, _ = sw_oracle.batch(w, (25, -50, -110, -6))
+        got_c, got_o = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"])
+        assert np.array_equal(got_o, want_o) and got_c == want_c
+
+
 def test_single_pair_entry_point(sw_engine, sw_oracle):
     """mgx_sw_align == SmithWaterman_align argument for argument, including short text buffers"""
     ref = np.frombuffer(b"ACGTACGTAAACCCGGGTTTACGATCGATCGGCTA", dtype=np.uint8)

@@ -11,8 +11,17 @@ for it in range(4):
     t0 = time.perf_counter()
     cig, off = eng.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"])
     dt = time.perf_counter() - t0
+    # the C call alone (no Python objects per pair)
+    import ctypes as C
+    nat = pkg.native
+    stride = 2 * 400 + 1
+    P = nat.SwParams(25, -50, -110, -6)
+    keep = [np.ascontiguousarray(w[k]) for k in ("ref_off", "ref", "alt_off", "alt", "strategy")]
+    inp = nat.SwInput(n, *[a.ctypes.data for a in keep])
+    o = np.empty(n, np.int32); cg = np.empty((n, stride), np.uint8)
+    t1 = time.perf_counter(); eng.lib.mgx_sw_align_batch(eng.ctx, C.byref(P), C.byref(inp), o.ctypes.data, cg.ctypes.data, stride, None); dc = time.perf_counter() - t1
     st = eng.stats()
-    print(f"run {it}: wall {dt*1e3:.1f} ms  fill {st['ms_fill']:.2f} ms  trace {st['ms_trace']:.2f} ms  cells {st['cells']/1e9:.3f} G "
+    print(f"run {it}: python {dt*1e3:.1f} ms  C call {dc*1e3:.1f} ms  fill {st['ms_fill']:.2f} ms  trace {st['ms_trace']:.2f} ms  cells {st['cells']/1e9:.3f} G "
           f"=> fill {st['cells']/st['ms_fill']/1e6:.1f} GCUPS, device {st['cells']/(st['ms_fill']+st['ms_trace'])/1e6:.1f} GCUPS, "
           f"backtrace {st['backtrace_bytes']/1e9:.2f} GB, launches {st['n_launches']}")
 from conftest import SmithWatermanRef
