@@ -24,6 +24,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/mgx_smithwaterman.h"
@@ -248,7 +249,7 @@ Shape shape_for(int nrow, bool paired) {
     for (int r : cls64) if (nrow <= 64 * r) return Shape{64, r};
     return Shape{0, 0};
 }
-constexpr u32 kPairedFrom = 65536;            // pairs in a chunk from which two share a wavefront
+constexpr u32 kPairedFrom = 32768;            // pairs in a chunk from which two share a wavefront
 constexpr int kCompactElems = 16;             // merged CIGAR elements copied back per pair without a second look
 inline u64 bt_bytes(u64 len1, u64 len2, const Shape& sh) {
     const u64 n_lanes = (len1 + sh.rpl - 1) / sh.rpl, steps = len2 + n_lanes - 1;
@@ -304,10 +305,14 @@ struct mgx_sw {
     DevBuf<GatherRef> d_gather;
     DevBuf<SwResult> d_res;
     mgx_sw_stats_t stats{};
+    void* pin = nullptr;          // pinned staging for the uploads (a pageable source is copied at a few GB/s)
+    size_t pin_cap = 0;
 };
 
 namespace {
-constexpr u64 kArenaLimit = 12ull << 30;      // back-trace bytes per chunk of a batch (MGX_SW_ARENA_LIMIT overrides, for tests)
+// back-trace bytes per chunk of a batch (MGX_SW_ARENA_LIMIT overrides).  Measured on 200 000 pairs: with 8-12 GB
+// chunks the call took 50-60 ms (a 20 ms stall follows every very large chunk), with 4 GB chunks 29 ms.
+constexpr u64 kArenaLimit = 4ull << 30;
 
 template <int G, int RPL>
 void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, u32 max_len2, SwParams P) {
@@ -338,16 +343,44 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         J.el_off = eln; eln += 2 * ((u64)J.len1 + J.len2 + 2);
     }
     // one fill launch per row class: sort the job list by rpl (stable; results go back through out_index)
-    std::stable_sort(jobs.begin(), jobs.end(), [](const SwJob& a, const SwJob& b) { return a.g * 64 + a.rpl < b.g * 64 + b.rpl; });
+    {   // counting sort by (g, rpl): a comparison sort of 10^5 jobs costs more than their alignments
+        auto cls = [](const SwJob& j) { return (j.g == 64 ? 64u : 0u) + j.rpl; };           // < 128
+        u32 cnt[129] = {0};
+        for (const SwJob& j : jobs) cnt[cls(j) + 1]++;
+        for (int k = 0; k < 128; ++k) cnt[k + 1] += cnt[k];
+        std::vector<SwJob> sorted(n);
+        for (const SwJob& j : jobs) sorted[cnt[cls(j)]++] = j;
+        jobs.swap(sorted);
+    }
     const u64 n1 = in->ref_off[hi] - base1, n2 = in->alt_off[hi] - base2;
     int rc;
     if ((rc = c->d_s1.reserve(n1 + 16)) || (rc = c->d_s2.reserve(n2 + 16)) || (rc = c->d_bt.reserve(bt + 16)) || (rc = c->d_jobs.reserve(n)) ||
         (rc = c->d_sc.reserve(scn)) || (rc = c->d_el.reserve(eln)) || (rc = c->d_res.reserve(n)) ||
         (rc = c->d_cel.reserve((size_t)n * 2 * kCompactElems))) return rc;
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_s1.p, in->ref + base1, n1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_s2.p, in->alt + base2, n2, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, jobs.data(), n * sizeof(SwJob), hipMemcpyHostToDevice, s));
+    {
+        const size_t a1 = (n1 + 255) & ~(size_t)255, a2 = (n2 + 255) & ~(size_t)255, total = a1 + a2 + n * sizeof(SwJob);
+        if (total > c->pin_cap) {
+            if (c->pin) (void)hipHostFree(c->pin);
+            c->pin = nullptr; c->pin_cap = 0;
+            HIP_TRY(hipHostMalloc(&c->pin, total + total / 4, hipHostMallocDefault));
+            c->pin_cap = total + total / 4;
+        }
+        char* pin = static_cast<char*>(c->pin);
+        const char* src[3] = {reinterpret_cast<const char*>(in->ref + base1), reinterpret_cast<const char*>(in->alt + base2),
+                              reinterpret_cast<const char*>(jobs.data())};
+        char* dst[3] = {pin, pin + a1, pin + a1 + a2};
+        const size_t len[3] = {(size_t)n1, (size_t)n2, n * sizeof(SwJob)};
+        if (total < (8u << 20)) { for (int k = 0; k < 3; ++k) memcpy(dst[k], src[k], len[k]); }
+        else {
+            std::thread th[3];
+            for (int k = 0; k < 3; ++k) th[k] = std::thread([=] { memcpy(dst[k], src[k], len[k]); });
+            for (auto& t : th) t.join();
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_s1.p, dst[0], n1, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_s2.p, dst[1], n2, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dst[2], n * sizeof(SwJob), hipMemcpyHostToDevice, s));
+    }
     const SwParams P{params->match, params->mismatch, params->gap_open, params->gap_extend};
     HIP_TRY(hipEventRecord(c->ev[0], s));
     for (u32 a = 0; a < n;) {
@@ -420,23 +453,38 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->stats.ms_fill += ms;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->stats.ms_trace += ms;
     c->stats.backtrace_bytes += bt;
-    for (u32 q = 0; q < n; ++q) {
-        const u64 p = lo + q;
-        const u32 l1 = (u32)(in->ref_off[p + 1] - in->ref_off[p]), l2 = (u32)(in->alt_off[p + 1] - in->alt_off[p]);
-        const SwResult& r = res[q];
-        out_offset[p] = r.offset;
-        if (out_score) out_score[p] = r.score;
-        if (out_cigar) {
-            char* dst = out_cigar + (size_t)p * stride;
-            const int cap = cap_override >= 0 ? cap_override
-                                              : (int)std::min<u64>(2ull * std::max(l1, l2), (u64)stride - 1);   // IntelSmithWaterman.cpp:8
-            const int16_t* src = cel.get() + (size_t)q * 2 * kCompactElems;
-            if (r.n_elems > kCompactElems) src = big.get() + big_at[q];
-            const int len = render(src, r.n_elems, dst, cap);
-            dst[len] = 0;                             // cap <= stride - 1
+    // results and CIGAR text, a few threads when the batch is large (rendering long element lists is
+    // the library's biggest host cost)
+    auto emit = [&](u32 q0, u32 q1, u64* cells_out) {
+        u64 cells = 0;
+        for (u32 q = q0; q < q1; ++q) {
+            const u64 p = lo + q;
+            const u32 l1 = (u32)(in->ref_off[p + 1] - in->ref_off[p]), l2 = (u32)(in->alt_off[p + 1] - in->alt_off[p]);
+            const SwResult& r = res[q];
+            out_offset[p] = r.offset;
+            if (out_score) out_score[p] = r.score;
+            if (out_cigar) {
+                char* dst = out_cigar + (size_t)p * stride;
+                const int cap = cap_override >= 0 ? cap_override
+                                                  : (int)std::min<u64>(2ull * std::max(l1, l2), (u64)stride - 1);   // IntelSmithWaterman.cpp:8
+                const int16_t* src = cel.get() + (size_t)q * 2 * kCompactElems;
+                if (r.n_elems > kCompactElems) src = big.get() + big_at[q];
+                const int len = render(src, r.n_elems, dst, cap);
+                dst[len] = 0;                             // cap <= stride - 1
+            }
+            cells += (u64)l1 * l2;
         }
-        c->stats.cells += (u64)l1 * l2;
+        *cells_out = cells;
+    };
+    constexpr u32 kThreads = 4;
+    u64 cells[kThreads] = {0};
+    if (n < 16384) emit(0, n, &cells[0]);
+    else {
+        std::thread th[kThreads];
+        for (u32 t = 0; t < kThreads; ++t) th[t] = std::thread(emit, (u32)((u64)n * t / kThreads), (u32)((u64)n * (t + 1) / kThreads), &cells[t]);
+        for (auto& t : th) t.join();
     }
+    for (u64 x : cells) c->stats.cells += x;
     return 0;
 }
 
@@ -470,6 +518,7 @@ void mgx_sw_destroy(mgx_sw_t* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->pin) (void)hipHostFree(c->pin);
     delete c;
 }
 
