@@ -224,3 +224,15 @@ def test_many_regions_in_one_batch(engine, synth):
     full = got[2]
     part = engine.compute_regions([sub])[0]
     assert np.array_equal(part, full[5:20, 3:11])
+
+
+def test_region_batch_with_empty_and_many_regions(engine, synth):
+    """an empty region inside the batch contributes nothing; a thousand small regions stay exact"""
+    regs = [synth.gen_pairhmm_region(6, 4, 500 + k, r_range=(20, 90), h_range=(40, 120)) for k in range(1000)]
+    empty = dict(regs[0]); empty["read_off"] = np.zeros(1, dtype=np.uint64)
+    regs.insert(500, empty)
+    got = engine.compute_regions(regs)
+    assert got[500].shape == (0, 4)
+    for k in (0, 1, 499, 501, 777, 1000):
+        d = dict(regs[k]); d["pair_read"] = None; d["pair_hap"] = None
+        assert np.array_equal(got[k], engine.compute(d).reshape(got[k].shape))
