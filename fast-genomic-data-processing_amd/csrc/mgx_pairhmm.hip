@@ -92,6 +92,7 @@ struct mgx_pairhmm_batch {
     uint32_t n_reads = 0, n_haps = 0;
     uint64_t* d_read_len = nullptr;
     uint8_t* d_keep = nullptr;
+    uint32_t *d_row_off = nullptr, *d_row_nh = nullptr;   // several regions in one batch: per-read output row
     size_t o_keep = 0;
     double log10_rate = 0, max_err = 0;
     hipEvent_t uploaded = nullptr;
@@ -450,7 +451,7 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
 // launches, one download.  Host work is linear in reads + haplotypes (the test cases are enumerated
 // on the device), so coalescing a thousand small regions costs microseconds, not a pair list.
 int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_input_t* regs, mgx_pairhmm_batch* b,
-                       std::vector<uint64_t>* out_base) {
+                       std::vector<uint64_t>* out_base, const uint8_t* const* mapq = nullptr, const mgx_read_model_t* model = nullptr) {
     uint64_t nr = 0, nh = 0, n = 0, read_bytes = 0, hap_bytes = 0;
     out_base->assign(n_regions + 1, 0);
     for (uint32_t g = 0; g < n_regions; ++g) {
@@ -529,11 +530,15 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
     const size_t o_del = off;   off = align_up(off + read_bytes);
     const size_t o_gcp = off;   off = align_up(off + read_bytes);
     const size_t o_hap = off;   off = align_up(off + hap_bytes);
+    const size_t o_mapq = off;  off = align_up(off + (model ? nr : 0));
+    const size_t o_rlen = off;  off = align_up(off + (model ? nr * sizeof(uint64_t) : 0));
+    const size_t o_roff = off;  off = align_up(off + (model ? nr * sizeof(uint32_t) : 0));
+    const size_t o_rnh = off;   off = align_up(off + (model ? nr * sizeof(uint32_t) : 0));
     b->in_bytes = off;
     const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
     b->o_out = off;             off = align_up(off + n * sizeof(double));
     b->o_used = off;            off = align_up(off + n);
-    b->o_keep = off;
+    b->o_keep = off;            off = align_up(off + (model ? nr : 0));
     b->result_bytes = off - b->o_out;
     const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
@@ -581,7 +586,43 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
         }
     }
     hipStream_t s = c->copy;
+    if (model) {
+        // per read, in global read order: MAPQ, length, and its row of the output
+        uint64_t* rlen = (uint64_t*)(pin + o_rlen);
+        uint32_t* roff = (uint32_t*)(pin + o_roff);
+        uint32_t* rnh = (uint32_t*)(pin + o_rnh);
+        uint64_t r_at = 0;
+        for (uint32_t g = 0; g < n_regions; ++g) {
+            const mgx_pairhmm_input_t& in = regs[g];
+            if (in.n_reads && !mapq[g]) { set_error("region %u: mapq is NULL", g); return -EINVAL; }
+            for (uint64_t r = 0; r < in.n_reads; ++r) {
+                const uint64_t len = in.read_off[r + 1] - in.read_off[r];
+                if (len > 1024) { set_error("read longer than 1024 bases"); return -E2BIG; }
+                rlen[r_at + r] = len;
+                roff[r_at + r] = (uint32_t)((*out_base)[g] + r * in.n_haps);
+                rnh[r_at + r] = (uint32_t)in.n_haps;
+            }
+            if (in.n_reads) memcpy(pin + o_mapq + r_at, mapq[g], in.n_reads);
+            r_at += in.n_reads;
+        }
+        b->has_model = true; b->n_reads = (uint32_t)nr; b->n_haps = 0;
+        b->d_read_len = (uint64_t*)(dv + o_rlen); b->d_keep = dv + b->o_keep;
+        b->d_row_off = (uint32_t*)(dv + o_roff); b->d_row_nh = (uint32_t*)(dv + o_rnh);
+        b->log10_rate = model->log10_mismapping_rate; b->max_err = model->max_error_per_base;
+    }
     HIP_TRY(hipMemcpyAsync(dv, pin, b->in_bytes, hipMemcpyHostToDevice, s));
+    if (model) {
+        ReadModel rm{};
+        rm.rate_factor = model->pcr_rate_factor; rm.bq_threshold = model->base_quality_threshold;
+        rm.constant_gcp = model->constant_gcp;
+        for (int i = 0; i <= 20; ++i) {      // PairHMMLikelihoodCalculationEngine.cpp:45-61
+            const double d = 40.0 - std::exp((double)i / ((double)std::max(rm.rate_factor, 1) * M_PI));
+            const int v = (d > 0.0 ? (int)(d + 0.5) : (int)(d - 0.5)) + 1;
+            rm.pcr_cache[i] = (uint8_t)(char)std::max(10, v);
+        }
+        hipLaunchKernelGGL(pairhmm_read_model, dim3((uint32_t)nr), dim3(128), 0, s, (const SeqRef*)(dv + o_rtab),
+                           b->d_bases, b->d_qual, b->d_ins, b->d_del, b->d_gcp, (const uint8_t*)(dv + o_mapq), rm);
+    }
     uint64_t job_begin = 0;
     for (int k = 0; k < kBins; ++k) {
         if (!reads_in[k]) continue;
@@ -800,7 +841,10 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 3], s));
         }
     }
-    if (b->has_model)
+    if (b->has_model && b->d_row_off)
+        hipLaunchKernelGGL(pairhmm_normalize_filter_rows, dim3((b->n_reads + 3) / 4), dim3(256), 0, s, b->d_out, b->d_read_len,
+                           b->d_row_off, b->d_row_nh, b->n_reads, b->log10_rate, b->max_err, b->d_keep);
+    else if (b->has_model)
         hipLaunchKernelGGL(pairhmm_normalize_filter, dim3((b->n_reads + 3) / 4), dim3(256), 0, s, b->d_out, b->d_read_len,
                            b->n_reads, b->n_haps, b->log10_rate, b->max_err, b->d_keep);
     HIP_TRY(hipGetLastError());
@@ -925,6 +969,46 @@ int mgx_pairhmm_compute(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, double*
     rc = mgx_pairhmm_batch_run(c, b);
     if (!rc) rc = mgx_pairhmm_batch_results(c, b, out_log10, nullptr);
     mgx_pairhmm_batch_destroy(c, b);
+    return rc;
+}
+
+int mgx_pairhmm_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_input_t* regions, const uint8_t* const* mapq,
+                        const mgx_read_model_t* model, double* const* out_log10, uint8_t* const* out_keep) {
+    if (!c || !model || (n_regions && (!regions || !mapq || !out_log10))) { set_error("NULL argument"); return -EINVAL; }
+    if (n_regions == 0) return 0;
+    int rc;
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        if ((rc = validate(&regions[g]))) return rc;
+        if (regions[g].n_reads * regions[g].n_haps && !out_log10[g]) { set_error("region %u: output pointer is NULL", g); return -EINVAL; }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
+        new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+    if (!b) return -ENOMEM;
+    std::vector<uint64_t> base;
+    if ((rc = create_cross_multi(c, n_regions, regions, b.get(), &base, mapq, model))) return rc;
+    if (b->n_pairs == 0) return 0;
+    mgx_pairhmm_batch* raw = b.release();
+    rc = mgx_pairhmm_batch_run(c, raw);
+    if (!rc) {
+        uint8_t* pin = raw->slab.pin;
+        rc = [&]() -> int {
+            HIP_TRY(hipMemcpyAsync(pin + raw->o_out, raw->d_out, raw->result_bytes, hipMemcpyDeviceToHost, c->compute));
+            HIP_TRY(hipStreamSynchronize(c->compute));
+            return 0;
+        }();
+        if (!rc) {
+            const double* all = (const double*)(pin + raw->o_out);
+            const uint8_t* keep = pin + raw->o_keep;
+            uint64_t r_at = 0;
+            for (uint32_t g = 0; g < n_regions; ++g) {
+                if (base[g + 1] > base[g]) memcpy(out_log10[g], all + base[g], (base[g + 1] - base[g]) * sizeof(double));
+                if (out_keep && out_keep[g] && regions[g].n_reads && regions[g].n_haps) memcpy(out_keep[g], keep + r_at, regions[g].n_reads);
+                r_at += regions[g].n_reads;
+            }
+        }
+    }
+    mgx_pairhmm_batch_destroy(c, raw);
     return rc;
 }
 

@@ -53,6 +53,7 @@ PAIRHMM_SYMBOLS = {
     "mgx_pairhmm_sync": (C.c_int, [C.c_void_p]),
     "mgx_read_model_defaults": (None, [C.c_void_p]),
     "mgx_pairhmm_region": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_regions": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_table_f32": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mgx_pairhmm_table_f64": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
 }

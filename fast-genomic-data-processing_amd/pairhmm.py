@@ -112,6 +112,29 @@ class PairHMMEngine:
         native.check(self.lib.mgx_pairhmm_compute_regions(self.ctx, n, C.cast(arr, C.c_void_p), C.cast(ptrs, C.c_void_p)))
         return outs
 
+    def regions(self, regions, mapqs, **model_overrides):
+        """Rows F1 + F2: computeReadLikelihoods for several regions in one device batch.
+        Returns [(log10 [n_reads][n_haps], keep [n_reads]) per region]."""
+        n = len(regions)
+        arr = (native.PairHMMInput * n)()
+        keeps, outs, kept, mqs = [], [], [], []
+        p_out, p_keep, p_mq = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for g, d in enumerate(regions):
+            d = dict(d); d["pair_read"] = None; d["pair_hap"] = None
+            inp, keep = make_input(d)
+            arr[g] = inp; keeps.append(keep)
+            o = np.empty((int(inp.n_reads), int(inp.n_haps)), dtype=np.float64); k = np.zeros(int(inp.n_reads), dtype=np.uint8)
+            mq = np.ascontiguousarray(mapqs[g], dtype=np.uint8)
+            outs.append(o); kept.append(k); mqs.append(mq)
+            p_out[g], p_keep[g], p_mq[g] = o.ctypes.data, k.ctypes.data, mq.ctypes.data
+        m = native.ReadModel()
+        self.lib.mgx_read_model_defaults(C.byref(m))
+        for k2, v in model_overrides.items():
+            setattr(m, k2, v)
+        native.check(self.lib.mgx_pairhmm_regions(self.ctx, n, C.cast(arr, C.c_void_p), C.cast(p_mq, C.c_void_p), C.byref(m),
+                                                  C.cast(p_out, C.c_void_p), C.cast(p_keep, C.c_void_p)))
+        return list(zip(outs, kept))
+
     def region(self, d, mapq, **model_overrides):
         """computeReadLikelihoods for one sample on the device: raw qualities in, normalised
         [n_reads][n_haps] log10 likelihoods and the keep mask of filterPoorlyModeledEvidence out."""

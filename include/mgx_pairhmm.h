@@ -146,6 +146,12 @@ void mgx_read_model_defaults(mgx_read_model_t* m);
 int mgx_pairhmm_region(mgx_pairhmm_t* ctx, const mgx_pairhmm_input_t* in, const uint8_t* mapq,
                        const mgx_read_model_t* model, double* out_log10, uint8_t* out_keep);
 
+/* Rows F1 + F2 together: the same for several regions (samples, active regions) in one device batch.
+ * mapq[g], out_log10[g], out_keep[g] belong to region g; out_keep and its entries may be NULL. */
+int mgx_pairhmm_regions(mgx_pairhmm_t* ctx, uint32_t n_regions, const mgx_pairhmm_input_t* regions,
+                        const uint8_t* const* mapq, const mgx_read_model_t* model,
+                        double* const* out_log10, uint8_t* const* out_keep);
+
 /* The two probability tables as built by the product (for table-parity tests):
  * which = 0: ph2pr[128]; which = 1: matchToMatchProb[32640].  Returns the element count. */
 int mgx_pairhmm_table_f32(int which, const float** out);

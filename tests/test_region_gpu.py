@@ -84,3 +84,21 @@ def test_region_model_off(engine, synth):
     got, keep = engine.region(d2, np.full(30, 255, dtype=np.uint8), pcr_rate_factor=0, constant_gcp=-1,
                               log10_mismapping_rate=float("-inf"))
     assert np.array_equal(got.ravel(), engine.compute(p2))
+
+
+def test_several_regions_in_one_batch(engine, synth):
+    """rows F1 + F2: mgx_pairhmm_regions returns, per region, exactly what mgx_pairhmm_region returns"""
+    shapes = [(60, 17, 11), (5, 1, 12), (200, 40, 13), (33, 7, 14)]
+    regs, mqs = [], []
+    for n_reads, n_haps, seed in shapes:
+        d, mapq = repeat_rich_region(synth, n_reads, n_haps, seed)
+        regs.append(d); mqs.append(mapq)
+    got = engine.regions(regs, mqs)
+    for d, mq, (o, k) in zip(regs, mqs, got):
+        wo, wk = engine.region(d, mq)
+        assert np.array_equal(o, wo) and np.array_equal(k, wk)
+    # a different model applies to all regions alike
+    got2 = engine.regions(regs[:2], mqs[:2], pcr_rate_factor=1, log10_mismapping_rate=-3.0)
+    for d, mq, (o, k) in zip(regs[:2], mqs[:2], got2):
+        wo, wk = engine.region(d, mq, pcr_rate_factor=1, log10_mismapping_rate=-3.0)
+        assert np.array_equal(o, wo) and np.array_equal(k, wk)
