@@ -1,0 +1,67 @@
+"""Randomised soak: loops over seeded random inputs for the three paths and compares the device with the
+oracles (bit-exact for sort/dedup and Smith-Waterman, 1e-5 for PairHMM).  usage: fuzz.py [seconds] [seed0]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("fast-genomic-data-processing_amd")
+synth = pkg.synth
+from conftest import PairHMMOracle, SortDedupOracle, SmithWatermanOracle, _ensure_oracle
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ph, sd, sw = pkg.PairHMMEngine(0), pkg.SortDedupEngine(0), pkg.SmithWatermanEngine(0)
+oph, osd, osw = PairHMMOracle(_ensure_oracle()), SortDedupOracle(), SmithWatermanOracle()
+rng = np.random.default_rng(seed0)
+t0 = time.time(); it = 0; fails = 0; counts = {"sort": 0, "pairhmm": 0, "regions": 0, "sw": 0}
+while time.time() - t0 < budget:
+    seed = int(rng.integers(1, 2**31 - 1)); it += 1
+    kind = it % 4
+    try:
+        if kind == 0:
+            kw = dict(n_contigs=int(rng.integers(1, 6)), contig_len=int(rng.choice([5000, 60000, 400000, 3000000])),
+                      dup_rate=float(rng.choice([0.0, 0.1, 0.5])), frag_rate=float(rng.choice([0.0, 0.05, 0.3])),
+                      supp_rate=float(rng.choice([0.0, 0.05])), cross_contig_rate=float(rng.choice([0.0, 0.05, 0.3])),
+                      ins_range=tuple(int(x) for x in rng.choice([[200, 600], [8000, 40000], [100, 70000]])),
+                      qname_style=str(rng.choice(["illumina7", "illumina6", "plain"])))
+            kw["ins_range"] = (kw["ins_range"][0], min(kw["ins_range"][1], max(kw["contig_len"] // 3, kw["ins_range"][0] + 1)))
+            if kw["contig_len"] <= 5000: kw["ins_range"] = (200, 600)
+            os.environ["MGX_SORTDEDUP_STREAMS"] = str(rng.choice(["1", "3"]))
+            raw = synth.gen_sortdedup_raw(int(rng.integers(1, 30000)), seed, **kw)
+            recs, idx, L = pkg.sortdedup.pack(raw)
+            wo, wd, _ = osd.run(L, recs)
+            o, d = sd.sort_mark(L, recs)
+            ok = np.array_equal(o, wo) and np.array_equal(d, wd)
+            counts["sort"] += 1
+        elif kind == 1:
+            n = int(rng.integers(1, 20000)); rmax = int(rng.choice([40, 128, 151, 300])); hmax = int(rng.choice([60, 256, 500]))
+            d = synth.gen_pairhmm_pairs(n, seed, r_range=(1, rmax), h_range=(1, hmax))
+            want, _ = oph.batch(d)
+            got = ph.compute(d)
+            fin = np.isfinite(want)
+            ok = np.array_equal(np.isfinite(got), fin) and (not fin.any() or float(np.abs(got[fin] - want[fin]).max()) <= 1e-5)
+            counts["pairhmm"] += 1
+        elif kind == 2:
+            regs = [synth.gen_pairhmm_region(int(rng.integers(1, 40)), int(rng.integers(1, 20)), seed + k, r_range=(10, int(rng.choice([60, 151, 260]))),
+                                             h_range=(20, 300)) for k in range(int(rng.integers(1, 12)))]
+            got = ph.compute_regions(regs)
+            ok = True
+            for dd, g in zip(regs, got):
+                d2 = dict(dd); d2["pair_read"] = None; d2["pair_hap"] = None
+                ok &= bool(np.array_equal(g, ph.compute(d2).reshape(g.shape)))
+            counts["regions"] += 1
+        else:
+            os.environ["MGX_SW_PAIRED"] = str(rng.choice(["0", "1"]))
+            w = synth.gen_sw_pairs(int(rng.integers(1, 400)), seed, ref_range=(1, int(rng.choice([60, 300, 700, 2048]))), alt_range=(1, int(rng.choice([40, 200, 600]))))
+            params = tuple(int(x) for x in rng.choice([[25, -50, -110, -6], [3, -1, -4, -3], [1, -2, -3, -1], [10, -15, -30, -5]]))
+            wc, wo, ws = osw.batch(w, params)
+            gc, go, gs = sw.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"], params, want_score=True)
+            ok = gc == wc and np.array_equal(go, wo) and np.array_equal(gs, ws)
+            counts["sw"] += 1
+    except Exception as e:            # noqa: BLE001
+        ok = False; print("EXCEPTION", kind, seed, repr(e), flush=True)
+    if not ok:
+        fails += 1; print("MISMATCH kind", kind, "seed", seed, flush=True)
+    if it % 50 == 0:
+        print(f"{it} iterations, {time.time() - t0:.0f} s, failures {fails}, {counts}", flush=True)
+print(f"done: {it} iterations in {time.time() - t0:.0f} s, failures {fails}, {counts}")
+sys.exit(1 if fails else 0)
