@@ -109,7 +109,8 @@ def test_product_does_not_reference_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".cpp", ".h", ".inc", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "oracle/" not in txt and "ph_oracle" not in txt and "libpairhmm_oracle" not in txt, f
+                for needle in ("oracle/", "ph_oracle", "sd_oracle", "sw_oracle", "_oracle.so", "libref_"):
+                    assert needle not in txt, (f, needle)
 
 
 def test_tandem_repeat_known_cases(oracle):
