@@ -26,7 +26,8 @@ while time.time() - t0 < budget:
             kw["ins_range"] = (kw["ins_range"][0], min(kw["ins_range"][1], max(kw["contig_len"] // 3, kw["ins_range"][0] + 1)))
             if kw["contig_len"] <= 5000: kw["ins_range"] = (200, 600)
             os.environ["MGX_SORTDEDUP_STREAMS"] = str(rng.choice(["1", "3"]))
-            raw = synth.gen_sortdedup_raw(int(rng.integers(1, 30000)), seed, **kw)
+            n_t = int(rng.integers(1, 30000)) if it % 40 else int(rng.integers(100000, 300000))      # now and then a larger one
+            raw = synth.gen_sortdedup_raw(n_t, seed, **kw)
             recs, idx, L = pkg.sortdedup.pack(raw)
             wo, wd, _ = osd.run(L, recs)
             o, d = sd.sort_mark(L, recs)
