@@ -87,6 +87,14 @@ extern "C" int mgx_sortdedup_pack(const mgx_raw_records_t* raw, mgx_rec_t* out, 
     if (!raw || !out_L || (raw->n_records && (!out || !out_input_index))) { mgx::set_error("NULL argument"); return -EINVAL; }
     const uint64_t n = raw->n_records;
     if (n >= 0xFFFFFFFFull) { mgx::set_error("more than 2^32-1 records"); return -E2BIG; }
+    if (n && (!raw->flag || !raw->tid || !raw->pos || !raw->cigar_off || !raw->qual_off || !raw->qname_off ||
+              (raw->n_targets && !raw->target_len))) { mgx::set_error("NULL array in raw records"); return -EINVAL; }
+    // offsets index host memory: a decreasing table would turn into an out-of-bounds read below
+    for (uint64_t r = 0; r < n; ++r)
+        if (raw->cigar_off[r + 1] < raw->cigar_off[r] || raw->qual_off[r + 1] < raw->qual_off[r] || raw->qname_off[r + 1] < raw->qname_off[r]) {
+            mgx::set_error("record %llu: offset table is not monotonic", (unsigned long long)r);
+            return -EINVAL;
+        }
     std::vector<uint64_t> ktable(raw->n_targets + 1);
     uint64_t acc = 0;
     for (uint32_t t = 0; t < raw->n_targets; ++t) { ktable[t] = acc; acc += raw->target_len[t]; }

@@ -93,3 +93,11 @@ def test_threaded_pack_equals_serial(pkg, sd_oracle, synth, monkeypatch):
         monkeypatch.setenv("MGX_PACK_THREADS", threads)
         recs, idx, L = pkg.sortdedup.pack(raw)
         assert L == oL and np.array_equal(idx, oidx) and recs.tobytes() == orecs.tobytes()
+
+
+def test_pack_rejects_decreasing_offsets(pkg, synth):
+    raw = synth.gen_sortdedup_raw(50, 3)
+    bad = dict(raw); bad["cigar_off"] = raw["cigar_off"].copy(); bad["cigar_off"][10] = bad["cigar_off"][12] + 5
+    import pytest
+    with pytest.raises(pkg.MgxError, match="monotonic"):
+        pkg.sortdedup.pack(bad)
