@@ -69,7 +69,8 @@ struct Scalars {
     alignas(128) u32 n_double; u32 pad1_[31];  // "far" double pairs (two-word keys)
     alignas(128) u32 n_single; u32 pad2_[31];
     alignas(128) u32 n_near;   u32 pad3_[31];
-    alignas(128) u32 n_multi_d; u32 n_multi_s, n_multi_n; u32 pad4_[29];   // run heads with more than one entry
+    alignas(128) u32 n_multi_d; u32 n_multi_s, n_multi_n;                   // run heads with more than one entry
+    u32 huge_runs; u32 pad4_[28];            // a position holds more near pairs than the in-run comparison accepts
 };
 // near pair: mate 5' end less than kNearSpan beyond record 1's (every proper pair; insert sizes are a
 // few hundred bases).  14 delta bits + 2 orientation bits + a 32-bit position = 48 key bits: six
@@ -84,6 +85,12 @@ constexpr int kNearScoreBits = 16;
 constexpr int kNearDeltaShift = kNearScoreBits;                       // delta
 constexpr int kNearOrientShift = kNearScoreBits + kNearDeltaBits;     // orientation
 constexpr int kNearShift = kNearOrientShift + 2;                      // record 1's 5' end
+// Near pairs are SORTED on record 1's 5' end alone (the upper 32 bits: four passes instead of six).  All
+// pairs that start at one position form a run; inside it the duplicate search groups by the remaining
+// identity bits (orientation, insert) by comparing every entry with every other one -- runs are two or
+// three entries, and a position with more than kHugeRun pairs (amplicon-like data) makes the whole
+// pipeline fall back to the full six-pass sort, where equal identities are adjacent.
+constexpr u32 kHugeRun = 4096;
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
@@ -691,7 +698,45 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
     const u32 total = *n_multi;
     for (u32 li = blockIdx.x * 256 + threadIdx.x; li < total; li += gridDim.x * 256) {
         const u32 i = multi_list[li];
-        if constexpr (KS > 0) {
+        if constexpr (KS > kNearScoreBits) {
+            // near pairs sorted on record 1's 5' end only: the run holds every pair that starts here; an
+            // entry loses to any other entry of the run with the same identity (bits above the score) and
+            // a better score -- tile, x, y, then arrival order on a score tie
+            const u64 run_id = k1[i] >> KS;
+            u32 j = i + 1;
+            for (; j < n && j - i < kWalkCap; ++j) if ((k1[j] >> KS) != run_id) break;
+            if (j < n && j - i >= kWalkCap && (k1[j] >> KS) == run_id) {
+                long_list[atomicAdd(n_long, 1u)] = i;                                 // long run: defer
+                continue;
+            }
+            for (u32 t = i; t < j; ++t) {
+                const u64 kt = k1[t];
+                const u64 idt = kt >> kNearScoreBits;
+                const u32 st = (u32)(kt & 0xFFFFu);
+                bool loser = false, have_t = false;
+                u32 rt = 0; u64 qt = 0;
+                for (u32 u = i; u < j && !loser; ++u) {
+                    if (u == t) continue;
+                    const u64 ku = k1[u];
+                    if ((ku >> kNearScoreBits) != idt) continue;
+                    const u32 su = (u32)(ku & 0xFFFFu);
+                    if (su < st) loser = true;
+                    else if (su == st) {
+                        if (!have_t) { rt = REC(t); const mgx_rec_t a = recs[rt]; qt = ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y; have_t = true; }
+                        const u32 ru = REC(u);
+                        const mgx_rec_t b = recs[ru];
+                        const u64 qu = ((u64)b.tile << 32) | ((u64)b.x << 16) | (u64)b.y;
+                        if (qu < qt || (qu == qt && ru < rt)) loser = true;
+                    }
+                }
+                if (loser) {
+                    if (!have_t) rt = REC(t);
+                    dup[rt] = 1;
+                    dup[recs[rt].mate] = 1;
+                }
+            }
+            continue;
+        } else if constexpr (KS > 0) {
             // near pairs: the low KS bits of the key word are 0xFFFF - pair score, so the best entry of
             // the run is known from the sorted keys; records are gathered only when several entries
             // share the best score (tile, x, y, then arrival order decide) and for the losers' mates
@@ -831,6 +876,60 @@ __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, c
     }
 }
 
+// long runs of the position-sorted near pairs: one workgroup per run, every entry against every other
+// (bounded by kHugeRun; beyond that the flag sends the whole pipeline to the six-pass sort)
+template <int RS>
+__global__ __launch_bounds__(256) void k_mark_long_sub(const u64* __restrict__ k1, const u32* __restrict__ rec, u32 n,
+                                                       const mgx_rec_t* __restrict__ recs, uint8_t* __restrict__ dup,
+                                                       const u32* __restrict__ long_list, const u32* n_long, u32* huge_runs) {
+    __shared__ u32 s_end;
+    for (u32 li = blockIdx.x; li < *n_long; li += gridDim.x) {
+        const u32 i = long_list[li];
+        const u64 run_id = k1[i] >> RS;
+        u32 end = n;
+        for (u32 c = i; c < n; c += 256) {                     // extent of the run
+            const u32 t = c + threadIdx.x;
+            if (threadIdx.x == 0) s_end = n;
+            __syncthreads();
+            if (t < n && (k1[t] >> RS) != run_id) atomicMin(&s_end, t);
+            __syncthreads();
+            const u32 e = s_end;
+            __syncthreads();
+            if (e < n) { end = e; break; }
+        }
+        if (end - i > kHugeRun) {
+            if (threadIdx.x == 0) atomicOr(huge_runs, 1u);
+            continue;
+        }
+        for (u32 t = i + threadIdx.x; t < end; t += 256) {
+            const u64 kt = k1[t];
+            const u64 idt = kt >> kNearScoreBits;
+            const u32 st = (u32)(kt & 0xFFFFu);
+            bool loser = false, have_t = false;
+            u32 rt = 0; u64 qt = 0;
+            for (u32 u = i; u < end && !loser; ++u) {
+                if (u == t) continue;
+                const u64 ku = k1[u];
+                if ((ku >> kNearScoreBits) != idt) continue;
+                const u32 su = (u32)(ku & 0xFFFFu);
+                if (su < st) loser = true;
+                else if (su == st) {
+                    if (!have_t) { rt = rec[t]; const mgx_rec_t a = recs[rt]; qt = ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y; have_t = true; }
+                    const u32 ru = rec[u];
+                    const mgx_rec_t b = recs[ru];
+                    const u64 qu = ((u64)b.tile << 32) | ((u64)b.x << 16) | (u64)b.y;
+                    if (qu < qt || (qu == qt && ru < rt)) loser = true;
+                }
+            }
+            if (loser) {
+                if (!have_t) rt = rec[t];
+                dup[rt] = 1;
+                dup[recs[rt].mate] = 1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_count_dup(const uint8_t* dup, u32 n, Scalars* sc) {
     // 16 flag bytes per load (the array comes from hipMalloc: 256-byte aligned); bytes are 0 or 1
     u32 c = 0;
@@ -884,6 +983,8 @@ struct mgx_sortdedup {
     bool packed_coord = false;             // L < 2^32: coordinate sort on packed (coord, index) words
     bool packed_pair = false;              // every 5' end < 2^32: (mate end, record) ride in one word
     bool ran = false;
+    bool near_by_position = true;          // near pairs sorted on record 1's 5' end only (MGX_SORTDEDUP_NEAR_EXACT=1: six-pass sort)
+    bool finished = false;                 // the results of the last run have been checked for the fallback
     int xcd_order = 1;                     // scatter tiles walk each XCD's contiguous range (MGX_SORTDEDUP_XCD_ORDER=0: plain)
     Scalars sc{};
     mgx_sortdedup_stats_t stats{};
@@ -990,8 +1091,12 @@ void launch_mark(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, 
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi);
     hipLaunchKernelGGL((k_mark_list<DOUBLE, PK, KS>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs, c->n,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, q.longl, n_long);
-    hipLaunchKernelGGL((k_mark_long<DOUBLE, PK, KS>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
-                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.longl, n_long);
+    if constexpr (KS > kNearScoreBits)
+        hipLaunchKernelGGL((k_mark_long_sub<KS>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, rec, n_entries, c->d_recs, c->d_dup, q.longl, n_long,
+                           &c->d_sc->huge_runs);
+    else
+        hipLaunchKernelGGL((k_mark_long<DOUBLE, PK, KS>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
+                           c->d_indicator, ind_bits, ind_off, c->d_dup, q.longl, n_long);
 }
 
 }  // namespace
@@ -1081,6 +1186,7 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
     }
     c->indicator_bits = 4 * L;
     c->L = L; c->n = (u32)n_records; c->ran = false;
+    c->near_by_position = true;             // decided again for every input (see finish_run)
     c->packed_coord = L < 0xFFFFFFFFull;     // coord <= L (bam_record.cpp:18-24)
     c->packed_pair = L < 0xF0000000ull;      // 5' ends <= L + clip; verified against the device maximum
     // records are streamed through two pinned staging buffers on the copy stream
@@ -1178,13 +1284,15 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     // other sorts' bandwidth-bound scatters.  In-process A/B on one device at 200 M records
     // (tools/dev_sort_ab.py): 18.0 ms against 19.4 ms on a single stream (MGX_SORTDEDUP_STREAMS=1).
     if (const char* e = getenv("MGX_SORTDEDUP_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
+    if (const char* e = getenv("MGX_SORTDEDUP_NEAR_EXACT")) { if (atoi(e) != 0) c->near_by_position = false; }
     const char* env_streams = getenv("MGX_SORTDEDUP_STREAMS");
     const bool multi = !(env_streams && atoi(env_streams) == 1);
     hipStream_t sN = (multi && tiled) ? c->side[0] : s;   // the atomic (non-tiled) bitmap needs the memset first
     hipStream_t sR = multi ? c->side[1] : s;
     int ncur = 0;
-    if ((rc = radix_sort(c, sN, c->scr[1], c->d_nk, nullptr, c->d_nrec, nn, kNearScoreBits,
-                         std::max(bits_of(c->sc.max_near) - kNearScoreBits, 1), &ncur))) return rc;
+    const int near_shift = c->near_by_position ? kNearShift : kNearScoreBits;
+    if ((rc = radix_sort(c, sN, c->scr[1], c->d_nk, nullptr, c->d_nrec, nn, near_shift,
+                         std::max(bits_of(c->sc.max_near) - near_shift, 1), &ncur))) return rc;
     bool defined = false;                     // has a pass already written every word of the tiled bitmap?
     if (tiled && n && c->packed_pair) {
         hipLaunchKernelGGL(k_indicator_tiles_near, dim3(n_ind_tiles), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, Lp);
@@ -1193,7 +1301,10 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
     }
     HIP_TRY(hipEventRecord(c->ev_ind, sN));
-    launch_mark<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
+    if (c->near_by_position)
+        launch_mark<true, false, kNearShift>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
+    else
+        launch_mark<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
     HIP_TRY(hipEventRecord(c->ev_side[0], sN));
 
     // records by unified coordinate (stable: equal coordinates keep arrival order)
@@ -1269,6 +1380,25 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     HIP_TRY(hipEventRecord(c->ev_stop, s));
     HIP_TRY(hipGetLastError());
     c->ran = true;
+    c->finished = false;
+    return 0;
+}
+
+// Waits for the pipeline and applies the one fallback that can only be decided afterwards: a position
+// holding more near pairs than the in-run comparison accepts sends the input through the pipeline again
+// with the six-pass near sort (equal identities adjacent, no quadratic step).
+static int finish_run(mgx_sortdedup_t* c) {
+    if (c->finished) return 0;
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipMemcpy(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost));
+    if (c->sc.huge_runs && c->near_by_position) {
+        c->near_by_position = false;
+        const int rc = mgx_sortdedup_run(c);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->compute));
+        HIP_TRY(hipMemcpy(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost));
+    }
+    c->finished = true;
     return 0;
 }
 
@@ -1276,6 +1406,7 @@ int mgx_sortdedup_results(mgx_sortdedup_t* c, uint32_t* out_order, uint8_t* out_
     if (!c) { set_error("ctx is NULL"); return -EINVAL; }
     if (!c->ran) { set_error("mgx_sortdedup_run has not been called"); return -EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = finish_run(c); if (rc) return rc; }
     if (c->n) {
         if (out_order) HIP_TRY(hipMemcpyAsync(out_order, c->d_cval[c->order_buf], (size_t)c->n * 4, hipMemcpyDeviceToHost, c->compute));
         if (out_dup) HIP_TRY(hipMemcpyAsync(out_dup, c->d_dup, (size_t)c->n, hipMemcpyDeviceToHost, c->compute));
@@ -1288,8 +1419,7 @@ int mgx_sortdedup_stats(mgx_sortdedup_t* c, mgx_sortdedup_stats_t* out) {
     if (!c || !out) { set_error("NULL argument"); return -EINVAL; }
     if (!c->ran) { set_error("mgx_sortdedup_run has not been called"); return -EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->compute));
-    HIP_TRY(hipMemcpy(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost));
+    { const int rc = finish_run(c); if (rc) return rc; }
     mgx_sortdedup_stats_t st = c->stats;
     st.n_dup_records = c->sc.n_dup;
     HIP_TRY(hipEventElapsedTime(&st.ms_total, c->ev_start, c->ev_stop));

@@ -25,6 +25,9 @@ def test_golden_file(pkg, sd_engine):
     (7, 24, {}), (1, 25, {}), (40000, 26, dict(n_contigs=2, contig_len=5000, dup_rate=0.0)),   # dense: long runs
     # inserts on both sides of the near-pair span (16 384): one-word and two-word pair keys side by side
     (30000, 27, dict(n_contigs=3, contig_len=400_000, ins_range=(8000, 40000), dup_rate=0.3)),
+    # ~200 pairs per start position with mixed orientations and inserts: the in-run grouping of the
+    # position-sorted near pairs, workgroup-per-run path
+    (40000, 28, dict(n_contigs=2, contig_len=3100, dup_rate=0.2)),
 ])
 def test_raw_random_vs_oracle(pkg, sd_engine, sd_oracle, synth, n_templates, seed, kw):
     raw = synth.gen_sortdedup_raw(n_templates, seed, **kw)
@@ -133,6 +136,41 @@ def test_full_size_properties(sd_engine, synth):
     dup_pairs = int(dup[first].sum(dtype=np.int64))
     assert dup_pairs == n_pairs - n_distinct
     assert st["n_double"] == n_pairs
+
+
+def test_near_sort_modes_agree(pkg, sd_oracle, synth, monkeypatch):
+    """near pairs sorted on the start position only (default) and the six-pass exact sort give the same
+    flags; a position with more pairs than the in-run comparison accepts falls back by itself"""
+    raw = synth.gen_sortdedup_raw(20000, 77, n_contigs=2, contig_len=20000, dup_rate=0.3)
+    recs, idx, L = pkg.sortdedup.pack(raw)
+    want_order, want_dup, _ = sd_oracle.run(L, recs)
+    for exact in ("0", "1"):
+        monkeypatch.setenv("MGX_SORTDEDUP_NEAR_EXACT", exact)
+        eng = pkg.SortDedupEngine(0)
+        order, dup = eng.sort_mark(L, recs)
+        st = eng.stats()
+        eng.close()
+        assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
+        assert st["n_radix_passes"] > 0
+    monkeypatch.delenv("MGX_SORTDEDUP_NEAR_EXACT")
+    # 6000 pairs starting at one position with three different inserts: beyond the in-run limit
+    n_t = 6000
+    big = np.zeros(2 * n_t, dtype=synth.REC_DTYPE)
+    a, b = big[0::2], big[1::2]
+    rng = np.random.RandomState(5)
+    a["prime5"] = 2000; b["prime5"] = 2300 + rng.randint(0, 3, n_t) * 7
+    a["coord"] = a["prime5"]; b["coord"] = b["prime5"] - 99
+    a["flag"] = 99; b["flag"] = 147
+    a["score"] = rng.randint(100, 400, n_t); b["score"] = rng.randint(100, 400, n_t)
+    a["x"] = b["x"] = rng.randint(0, 50, n_t)
+    ar = np.arange(n_t, dtype=np.uint32) * 2
+    a["mate"], b["mate"] = ar + 1, ar
+    want_order, want_dup, _ = sd_oracle.run(50000, big)
+    eng = pkg.SortDedupEngine(0)
+    order, dup = eng.sort_mark(50000, big)
+    eng.close()
+    assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
+    assert dup.sum() == 2 * (n_t - 3)
 
 
 def test_empty_input(sd_engine, synth):
