@@ -134,7 +134,6 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
                 if (ff > h) { op = kOpDelete; h = ff; }
                 diag = hl[k]; hl[k] = h; e[k] = ee; up_h = h; up_f = ff;
                 packed[k >> 2] |= (u32)(op | ext) << ((k & 3) * 8);
-                if (j == ncol && r0 + k + 1 <= nrow) last_col[r0 + k + 1] = h;
             }
             send_h = up_h; send_f = up_f;
             if (lane == lane_last) {
@@ -151,6 +150,12 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
                 for (int q = 0; q < RPL / 4; ++q) reinterpret_cast<u32*>(dst)[q] = packed[q];
             }
         }
+    }
+    // a lane's last active step is column ncol: its registers now hold H(i, ncol) (kept out of the loop --
+    // a guarded store per cell and step doubled the instruction count of the sweep)
+    if (lane < n_lanes) {
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) if (r0 + k + 1 <= nrow) last_col[r0 + k + 1] = hl[k];
     }
 }
 
