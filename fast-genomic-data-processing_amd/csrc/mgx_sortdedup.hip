@@ -640,15 +640,12 @@ __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, c
                                                    const u32* __restrict__ rec, u32 n,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
                                                    uint8_t* __restrict__ dup, u32* __restrict__ multi_list, u32* n_multi) {
-    __shared__ u32 s_cnt, s_base;
+    __shared__ u32 s_base;
+    __shared__ u32 s_scan[4];
     // near pairs come as DOUBLE with k2 == nullptr: the single key word is the whole identity
     auto K2 = [&](u32 t) -> u64 { return (!DOUBLE || !k2) ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
     auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
     const u32 base = blockIdx.x * (256 * kFindItems);
-    const u64 lt = lanemask_lt();
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    u32 slot[kFindItems];
     u32 is_multi = 0;
 #pragma unroll
     for (int k = 0; k < kFindItems; ++k) {
@@ -672,19 +669,18 @@ __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, c
                 }
             }
         }
-        const u64 bm = __ballot(multi);
-        u32 wbase = 0;
-        if ((threadIdx.x & 63) == 0 && bm) wbase = atomicAdd(&s_cnt, (u32)__popcll(bm));
-        wbase = __shfl(wbase, 0, 64);
-        slot[k] = wbase + (u32)__popcll(bm & lt);
         is_multi |= (multi ? 1u : 0u) << k;
     }
+    // one block scan over the per-thread counts (instead of a ballot + LDS atomic per item), one global
+    // atomic per workgroup; the list's order is irrelevant
+    u32 total;
+    u32 at = block_excl_scan_256((u32)__popc(is_multi), s_scan, &total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(n_multi, total) : 0u;
     __syncthreads();
-    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(n_multi, s_cnt) : 0u;
-    __syncthreads();
+    at += s_base;
 #pragma unroll
     for (int k = 0; k < kFindItems; ++k)
-        if ((is_multi >> k) & 1u) multi_list[s_base + slot[k]] = base + k * 256 + threadIdx.x;
+        if ((is_multi >> k) & 1u) multi_list[at++] = base + k * 256 + threadIdx.x;
 }
 
 template <bool DOUBLE, bool PK, int KS>
