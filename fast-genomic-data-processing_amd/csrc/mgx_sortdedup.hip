@@ -560,19 +560,23 @@ __global__ __launch_bounds__(256) void k_indicator_tiles(const u64* __restrict__
 // pass.  A pair's record-1 end lies in the tile of p1, its record-2 end at p1 + delta < p1 + kNearSpan in
 // that tile or the next, so tile t scans the entries with p1 in [t*65536 - (kNearSpan - 1), (t+1)*65536).
 // Always the first pass over the bitmap: defines every word.
-__global__ __launch_bounds__(256) void k_indicator_tiles_near(const u64* __restrict__ nk, u32 n, u32* __restrict__ indicator, u64 Lp) {
+// sub_start[x] = first sorted entry whose record-1 end is at or beyond x * kNearSpan (written by k_find_runs):
+// the tile's slice of the entries without two 27-step binary searches per workgroup.
+__global__ __launch_bounds__(256) void k_indicator_tiles_near(const u64* __restrict__ nk, u32 n, u32* __restrict__ indicator, u64 Lp,
+                                                              const u32* __restrict__ sub_start, u32 n_sub) {
     __shared__ u32 fw[kIndTile / 32], rv[kIndTile / 32];
     __shared__ u32 s_lo, s_hi;
     for (u32 w = threadIdx.x; w < kIndTile / 32; w += 256) { fw[w] = 0; rv[w] = 0; }
     const u64 pos_lo = (u64)blockIdx.x * kIndTile, pos_hi = pos_lo + kIndTile;
-    if (threadIdx.x < 2) {
-        const u64 target = threadIdx.x == 0 ? (pos_lo >= kNearSpan - 1 ? pos_lo - (kNearSpan - 1) : 0ull) : pos_hi;
-        u32 a = 0, b = n;
-        while (a < b) { const u32 m = a + (b - a) / 2; if ((nk[m] >> kNearShift) < target) a = m + 1; else b = m; }
-        if (threadIdx.x == 0) s_lo = a; else s_hi = a;
+    constexpr u32 kSubPerTile = kIndTile / (u32)kNearSpan;
+    if (threadIdx.x == 0) {
+        // entries with p1 >= pos_lo - kNearSpan (a superset of the pairs whose second end can reach this tile) ...
+        s_lo = blockIdx.x == 0 ? 0u : sub_start[blockIdx.x * kSubPerTile - 1];
+        // ... up to the first entry at or beyond pos_hi
+        s_hi = sub_start[min((blockIdx.x + 1) * kSubPerTile, n_sub)];
     }
     __syncthreads();
-    const u32 lo = s_lo, hi = s_hi;
+    const u32 lo = s_lo, hi = min(s_hi, n);
     for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
         const u64 key = nk[i];
         const u64 p1 = key >> kNearShift, p2 = p1 + ((key >> kNearDeltaShift) & (kNearSpan - 1));
@@ -639,7 +643,8 @@ template <bool DOUBLE, bool PK, int KS>
 __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, const u64* __restrict__ k2,
                                                    const u32* __restrict__ rec, u32 n,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
-                                                   uint8_t* __restrict__ dup, u32* __restrict__ multi_list, u32* n_multi) {
+                                                   uint8_t* __restrict__ dup, u32* __restrict__ multi_list, u32* n_multi,
+                                                   u32* __restrict__ sub_start, u32 n_sub) {
     __shared__ u32 s_base;
     __shared__ u32 s_scan[4];
     // near pairs come as DOUBLE with k2 == nullptr: the single key word is the whole identity
@@ -658,6 +663,15 @@ __global__ __launch_bounds__(256) void k_find_runs(const u64* __restrict__ k1, c
         u64 n1 = __shfl_down(a1, 1, 64), n2 = DOUBLE ? __shfl_down(a2, 1, 64) : 0ull;
         if (lane == 0 && i > 0 && i < n) { p1 = k1[i - 1] >> KS; p2 = K2(i - 1); }
         if (lane == 63 && i + 1 < n) { n1 = k1[i + 1] >> KS; n2 = K2(i + 1); }
+        if constexpr (KS >= kNearScoreBits) {
+            // near pairs: where the sorted entries cross a kNearSpan boundary of the genome (for the bitmap pass)
+            if (sub_start && i < n) {
+                const u32 cur = (u32)((a1 >> (kNearShift - KS)) >> kNearDeltaBits);
+                const int prev = i == 0 ? -1 : (int)((p1 >> (kNearShift - KS)) >> kNearDeltaBits);
+                for (int x = prev + 1; x <= (int)cur && x <= (int)n_sub; ++x) sub_start[x] = i;
+                if (i == n - 1) for (u32 x = cur + 1; x <= n_sub; ++x) sub_start[x] = n;
+            }
+        }
         if (i < n) {
             const bool head = i == 0 || p1 != a1 || (DOUBLE && p2 != a2);
             if (head) {
@@ -964,6 +978,7 @@ struct mgx_sortdedup {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_ind = nullptr, ev_side[2] = {nullptr, nullptr};
     u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
+    u32* d_sub_start = nullptr; size_t sub_cap = 0;      // first near entry per kNearSpan positions (bitmap pass)
     uint8_t* d_dup = nullptr;
     Scalars* d_sc = nullptr;
     void* pinned[2] = {nullptr, nullptr};
@@ -1079,12 +1094,19 @@ int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q,
 
 // duplicate search over one sorted entry array: run heads -> dense list -> marks (+ long runs)
 template <bool DOUBLE, bool PK, int KS = 0>
-void launch_mark(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, const u32* rec, u32 n_entries,
-                 const mgx_sortdedup::Scratch& q, u32* n_multi, u32* n_long, u64 ind_bits, u64 ind_off) {
+void launch_find(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, const u32* rec, u32 n_entries,
+                 const mgx_sortdedup::Scratch& q, u32* n_multi, u64 ind_bits, u64 ind_off, u32* sub_start = nullptr, u32 n_sub = 0) {
     if (!n_entries) return;
     const u32 per = 256 * kFindItems;
     hipLaunchKernelGGL((k_find_runs<DOUBLE, PK, KS>), dim3((n_entries + per - 1) / per), dim3(256), 0, s, k1, k2, rec, n_entries,
-                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi);
+                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, sub_start, n_sub);
+}
+
+template <bool DOUBLE, bool PK, int KS = 0>
+void launch_mark(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, const u32* rec, u32 n_entries,
+                 const mgx_sortdedup::Scratch& q, u32* n_multi, u32* n_long, u64 ind_bits, u64 ind_off, bool find_done = false) {
+    if (!n_entries) return;
+    if (!find_done) launch_find<DOUBLE, PK, KS>(c, s, k1, k2, rec, n_entries, q, n_multi, ind_bits, ind_off);
     hipLaunchKernelGGL((k_mark_list<DOUBLE, PK, KS>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs, c->n,
                        c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, q.longl, n_long);
     if constexpr (KS > kNearScoreBits)
@@ -1152,7 +1174,7 @@ void mgx_sortdedup_destroy(mgx_sortdedup_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_buffers(c);
-    (void)hipFree(c->d_indicator); (void)hipFree(c->d_sc);
+    (void)hipFree(c->d_indicator); (void)hipFree(c->d_sub_start); (void)hipFree(c->d_sc);
     for (int i = 0; i < 2; ++i) { if (c->pinned[i]) (void)hipHostFree(c->pinned[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
     for (auto e : c->ev_scatter) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1179,6 +1201,14 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
         (void)hipFree(c->d_indicator); c->d_indicator = nullptr; c->indicator_cap_words = 0;
         HIP_TRY(hipMalloc((void**)&c->d_indicator, words * 4));
         c->indicator_cap_words = words;
+    }
+    {
+        const size_t n_sub = (size_t)(Lp / kNearSpan) + 2;
+        if (n_sub > c->sub_cap) {
+            (void)hipFree(c->d_sub_start); c->d_sub_start = nullptr; c->sub_cap = 0;
+            HIP_TRY(hipMalloc((void**)&c->d_sub_start, n_sub * 4));
+            c->sub_cap = n_sub;
+        }
     }
     c->indicator_bits = 4 * L;
     c->L = L; c->n = (u32)n_records; c->ran = false;
@@ -1290,17 +1320,27 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     if ((rc = radix_sort(c, sN, c->scr[1], c->d_nk, nullptr, c->d_nrec, nn, near_shift,
                          std::max(bits_of(c->sc.max_near) - near_shift, 1), &ncur))) return rc;
     bool defined = false;                     // has a pass already written every word of the tiled bitmap?
-    if (tiled && n && c->packed_pair) {
-        hipLaunchKernelGGL(k_indicator_tiles_near, dim3(n_ind_tiles), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, Lp);
+    const bool near_tiles = tiled && n && c->packed_pair;
+    const u32 n_sub = (u32)(Lp / kNearSpan);
+    // run heads first: the same pass over the sorted keys notes where they cross the bitmap's sub-tile boundaries
+    if (near_tiles && !nn) HIP_TRY(hipMemsetAsync(c->d_sub_start, 0, ((size_t)n_sub + 1) * 4, sN));
+    if (c->near_by_position)
+        launch_find<true, false, kNearShift>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, ind_bits, ind_off,
+                                             near_tiles ? c->d_sub_start : nullptr, n_sub);
+    else
+        launch_find<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, ind_bits, ind_off,
+                                                 near_tiles ? c->d_sub_start : nullptr, n_sub);
+    if (near_tiles) {
+        hipLaunchKernelGGL(k_indicator_tiles_near, dim3(n_ind_tiles), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, Lp, c->d_sub_start, n_sub);
         defined = true;
     } else if (!tiled && nn) {
         hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
     }
     HIP_TRY(hipEventRecord(c->ev_ind, sN));
     if (c->near_by_position)
-        launch_mark<true, false, kNearShift>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
+        launch_mark<true, false, kNearShift>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off, true);
     else
-        launch_mark<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off);
+        launch_mark<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off, true);
     HIP_TRY(hipEventRecord(c->ev_side[0], sN));
 
     // records by unified coordinate (stable: equal coordinates keep arrival order)
