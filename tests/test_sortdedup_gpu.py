@@ -168,9 +168,14 @@ def test_near_sort_modes_agree(pkg, sd_oracle, synth, monkeypatch):
     want_order, want_dup, _ = sd_oracle.run(50000, big)
     eng = pkg.SortDedupEngine(0)
     order, dup = eng.sort_mark(50000, big)
-    eng.close()
     assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
     assert dup.sum() == 2 * (n_t - 3)
+    # the fallback is also taken when the statistics are asked for before the results
+    eng.upload(50000, big); eng.run()
+    assert eng.stats()["n_dup_records"] == 2 * (n_t - 3)
+    order, dup = eng.results()
+    eng.close()
+    assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
 
 
 def test_empty_input(sd_engine, synth):
