@@ -129,6 +129,7 @@ struct BuildOut {
     int packed_pair;                      // dk2 = mate 5' end << 32 | record (every 5' end < 2^32)
     u64* nk; u32* nrec;                   // near double pairs: one key word p1 << 32 | orient << 30 | (p2 - p1) << 16 | inverted pair score
     int near_enabled;
+    u32 mate_flag;                        // 0x80000000 when record indices leave bit 31 free: "the mate is the neighbour rec ^ 1"
 };
 
 // Entries are compacted with one global atomic per workgroup and kind, so their order is not the
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
         const u32 i = base + k * 256 + threadIdx.x;
         if (cls[k] == 3) {
             const u32 at = s_base[2] + slot[k];
-            o.nk[at] = ka[k]; o.nrec[at] = i;
+            o.nk[at] = ka[k]; o.nrec[at] = i | (mate[k] == (i ^ 1u) ? o.mate_flag : 0u);
         } else if (cls[k] == 1) {
             const u32 at = s_base[0] + slot[k];
             o.dk1[at] = ka[k];
@@ -702,9 +703,11 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
                                                    const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs, u32 n_records,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
                                                    uint8_t* __restrict__ dup, const u32* __restrict__ multi_list, const u32* n_multi,
-                                                   u32* __restrict__ long_list, u32* n_long) {
+                                                   u32* __restrict__ long_list, u32* n_long, u32 rec_mask) {
+    // rec_mask: near-pair record words carry "the mate is the neighbour" in the bits outside the mask
     auto K2 = [&](u32 t) -> u64 { return (!DOUBLE || !k2) ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
-    auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
+    auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t] & rec_mask; };
+    auto MATE = [&](u32 t, u32 r) -> u32 { return (!PK && (rec[t] & ~rec_mask)) ? (r ^ 1u) : recs[r].mate; };
     const u32 total = *n_multi;
     for (u32 li = blockIdx.x * 256 + threadIdx.x; li < total; li += gridDim.x * 256) {
         const u32 i = multi_list[li];
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
                 if (loser) {
                     if (!have_t) rt = REC(t);
                     dup[rt] = 1;
-                    dup[recs[rt].mate] = 1;
+                    dup[MATE(t, rt)] = 1;
                 }
             }
             continue;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
                 if (t == best) continue;
                 const u32 r = REC(t);
                 dup[r] = 1;
-                dup[recs[r].mate] = 1;
+                dup[MATE(t, r)] = 1;
             }
             continue;
         }
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
             if (t == best) continue;
             const u32 r = REC(t);
             dup[r] = 1;
-            if (DOUBLE) dup[recs[r].mate] = 1;
+            if (DOUBLE) dup[MATE(t, r)] = 1;
         }
     }
 }
@@ -833,13 +836,13 @@ template <bool DOUBLE, bool PK, int KS>
 __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, const u64* __restrict__ k2,
                                                    const u32* __restrict__ rec, u32 n, const mgx_rec_t* __restrict__ recs,
                                                    const u32* __restrict__ indicator, u64 indicator_bits, u64 L,
-                                                   uint8_t* __restrict__ dup, const u32* __restrict__ long_list, const u32* n_long) {
+                                                   uint8_t* __restrict__ dup, const u32* __restrict__ long_list, const u32* n_long, u32 rec_mask) {
     __shared__ u64 sq[256];
     __shared__ u32 sp[256];
     __shared__ u32 sr[256];
     __shared__ u32 s_end;
     auto K2 = [&](u32 t) -> u64 { return (!DOUBLE || !k2) ? 0ull : (PK ? (k2[t] >> 32) : k2[t]); };
-    auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t]; };
+    auto REC = [&](u32 t) -> u32 { return PK ? (u32)k2[t] : rec[t] & rec_mask; };
     for (u32 li = blockIdx.x; li < *n_long; li += gridDim.x) {
         const u32 i = long_list[li];
         const u64 a1 = k1[i] >> KS, a2 = K2(i);          // KS: key bits below the identity
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, c
             if (t == best) continue;
             const u32 r = REC(t);
             dup[r] = 1;
-            if (DOUBLE) dup[recs[r].mate] = 1;
+            if (DOUBLE) dup[(!PK && (rec[t] & ~rec_mask)) ? (r ^ 1u) : recs[r].mate] = 1;
         }
         __syncthreads();
     }
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(256) void k_mark_long(const u64* __restrict__ k1, c
 template <int RS>
 __global__ __launch_bounds__(256) void k_mark_long_sub(const u64* __restrict__ k1, const u32* __restrict__ rec, u32 n,
                                                        const mgx_rec_t* __restrict__ recs, uint8_t* __restrict__ dup,
-                                                       const u32* __restrict__ long_list, const u32* n_long, u32* huge_runs) {
+                                                       const u32* __restrict__ long_list, const u32* n_long, u32* huge_runs, u32 rec_mask) {
     __shared__ u32 s_end;
     for (u32 li = blockIdx.x; li < *n_long; li += gridDim.x) {
         const u32 i = long_list[li];
@@ -924,17 +927,17 @@ __global__ __launch_bounds__(256) void k_mark_long_sub(const u64* __restrict__ k
                 const u32 su = (u32)(ku & 0xFFFFu);
                 if (su < st) loser = true;
                 else if (su == st) {
-                    if (!have_t) { rt = rec[t]; const mgx_rec_t a = recs[rt]; qt = ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y; have_t = true; }
-                    const u32 ru = rec[u];
+                    if (!have_t) { rt = rec[t] & rec_mask; const mgx_rec_t a = recs[rt]; qt = ((u64)a.tile << 32) | ((u64)a.x << 16) | (u64)a.y; have_t = true; }
+                    const u32 ru = rec[u] & rec_mask;
                     const mgx_rec_t b = recs[ru];
                     const u64 qu = ((u64)b.tile << 32) | ((u64)b.x << 16) | (u64)b.y;
                     if (qu < qt || (qu == qt && ru < rt)) loser = true;
                 }
             }
             if (loser) {
-                if (!have_t) rt = rec[t];
+                if (!have_t) rt = rec[t] & rec_mask;
                 dup[rt] = 1;
-                dup[recs[rt].mate] = 1;
+                dup[(rec[t] & ~rec_mask) ? (rt ^ 1u) : recs[rt].mate] = 1;
             }
         }
     }
@@ -1104,17 +1107,18 @@ void launch_find(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, 
 
 template <bool DOUBLE, bool PK, int KS = 0>
 void launch_mark(mgx_sortdedup* c, hipStream_t s, const u64* k1, const u64* k2, const u32* rec, u32 n_entries,
-                 const mgx_sortdedup::Scratch& q, u32* n_multi, u32* n_long, u64 ind_bits, u64 ind_off, bool find_done = false) {
+                 const mgx_sortdedup::Scratch& q, u32* n_multi, u32* n_long, u64 ind_bits, u64 ind_off, bool find_done = false,
+                 u32 rec_mask = 0xFFFFFFFFu) {
     if (!n_entries) return;
     if (!find_done) launch_find<DOUBLE, PK, KS>(c, s, k1, k2, rec, n_entries, q, n_multi, ind_bits, ind_off);
     hipLaunchKernelGGL((k_mark_list<DOUBLE, PK, KS>), dim3(c->n_cu * 16), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs, c->n,
-                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, q.longl, n_long);
+                       c->d_indicator, ind_bits, ind_off, c->d_dup, q.multi, n_multi, q.longl, n_long, rec_mask);
     if constexpr (KS > kNearScoreBits)
         hipLaunchKernelGGL((k_mark_long_sub<KS>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, rec, n_entries, c->d_recs, c->d_dup, q.longl, n_long,
-                           &c->d_sc->huge_runs);
+                           &c->d_sc->huge_runs, rec_mask);
     else
         hipLaunchKernelGGL((k_mark_long<DOUBLE, PK, KS>), dim3(c->n_cu * 2), dim3(256), 0, s, k1, k2, rec, n_entries, c->d_recs,
-                           c->d_indicator, ind_bits, ind_off, c->d_dup, q.longl, n_long);
+                           c->d_indicator, ind_bits, ind_off, c->d_dup, q.longl, n_long, rec_mask);
 }
 
 }  // namespace
@@ -1268,7 +1272,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
             const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
             BuildOut o{c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
                        c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0, c->packed_pair ? 1 : 0,
-                       c->d_nk[0], c->d_nrec[0], c->packed_pair ? 1 : 0};
+                       c->d_nk[0], c->d_nrec[0], c->packed_pair ? 1 : 0, n < 0x80000000u ? 0x80000000u : 0u};
             hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, o, c->d_sc);
             HIP_TRY(hipGetLastError());
         }
@@ -1337,10 +1341,11 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         hipLaunchKernelGGL(k_set_indicator_near, dim3((nn + 255) / 256), dim3(256), 0, sN, c->d_nk[ncur], nn, c->d_indicator, c->indicator_bits, c->L);
     }
     HIP_TRY(hipEventRecord(c->ev_ind, sN));
+    const u32 near_rec_mask = n < 0x80000000u ? 0x7FFFFFFFu : 0xFFFFFFFFu;
     if (c->near_by_position)
-        launch_mark<true, false, kNearShift>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off, true);
+        launch_mark<true, false, kNearShift>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off, true, near_rec_mask);
     else
-        launch_mark<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off, true);
+        launch_mark<true, false, kNearScoreBits>(c, sN, c->d_nk[ncur], nullptr, c->d_nrec[ncur], nn, c->scr[1], &c->d_sc->n_multi_n, &c->d_sc->n_long_n, ind_bits, ind_off, true, near_rec_mask);
     HIP_TRY(hipEventRecord(c->ev_side[0], sN));
 
     // records by unified coordinate (stable: equal coordinates keep arrival order)
