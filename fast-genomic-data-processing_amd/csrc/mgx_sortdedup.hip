@@ -613,6 +613,12 @@ __global__ __launch_bounds__(256) void k_set_indicator_near(const u64* __restric
 // ---------------------------------------------------------------------------------------------
 // best-of-run and duplicate marking
 // ---------------------------------------------------------------------------------------------
+// both records of a losing pair: one 2-byte store when the mate is the neighbour (flag in the record word)
+__device__ __forceinline__ void mark_pair(uint8_t* dup, const mgx_rec_t* recs, u32 r, bool neighbour) {
+    if (neighbour) reinterpret_cast<uint16_t*>(dup)[r >> 1] = 0x0101;
+    else { dup[r] = 1; dup[recs[r].mate] = 1; }
+}
+
 // quality of a pair entry: smaller is better -- score descending, then tile, x, y ascending
 // (main.cpp:253-264 / 303-314); the record index (= arrival order) breaks total ties
 __device__ __forceinline__ u64 quality_word(uint16_t score, const mgx_rec_t& a) {
@@ -744,8 +750,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
                 }
                 if (loser) {
                     if (!have_t) rt = REC(t);
-                    dup[rt] = 1;
-                    dup[MATE(t, rt)] = 1;
+                    mark_pair(dup, recs, rt, !PK && (rec[t] & ~rec_mask));
                 }
             }
             continue;
@@ -781,8 +786,7 @@ __global__ __launch_bounds__(256) void k_mark_list(const u64* __restrict__ k1, c
             for (u32 t = i; t < j; ++t) {
                 if (t == best) continue;
                 const u32 r = REC(t);
-                dup[r] = 1;
-                dup[MATE(t, r)] = 1;
+                mark_pair(dup, recs, r, !PK && (rec[t] & ~rec_mask));
             }
             continue;
         }
@@ -936,8 +940,7 @@ __global__ __launch_bounds__(256) void k_mark_long_sub(const u64* __restrict__ k
             }
             if (loser) {
                 if (!have_t) rt = rec[t] & rec_mask;
-                dup[rt] = 1;
-                dup[(rec[t] & ~rec_mask) ? (rt ^ 1u) : recs[rt].mate] = 1;
+                mark_pair(dup, recs, rt, (rec[t] & ~rec_mask) != 0);
             }
         }
     }
