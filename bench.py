@@ -1,13 +1,19 @@
-"""Headline benchmark: PairHMM GCUPS on BASELINE.json configs[1] (1M synthetic test cases,
-read 128 x haplotype 256, fp32 with fp64 re-run) per GPU; one process per GPU, no collectives on
-the data path (test cases are independent -> ranks own disjoint shards, "weak" scaling).
+"""Headline benchmark (driver contract: one process per GPU, rank 0 prints ONE JSON line).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over the resident batch: the fp32 recurrence kernel over all
-test cases plus the fp64 re-run of those that underflowed, with results left in HBM.  Inputs are
-uploaded before the timed region.  Rank 0 prints ONE JSON line.
+PairHMM (`value`, GCUPS):
+  N = 1  BASELINE.json configs[1]: 1M synthetic test cases, read 128 x haplotype 256 (sub-run 2a), resident in HBM.
+  N > 1  BASELINE.json configs[2]: ONE stream of 64M test cases split over the N ranks (64M / N per GPU, each rank
+         generates only its shard), every shard resident in HBM; no collective on the data path -- torch.distributed
+         only provides the barrier and the max-over-ranks of the timed region.
+  A "step" is one pass of the hot path over the resident shard: the fp32 recurrence kernel over all test cases plus
+  the fp64 re-run of those that underflowed, results left in HBM.  Inputs are uploaded before the timed region.
+  Next to it: "queue" = the same shard streamed from host memory through the host work queue (65536-test-case
+  batches, packing/H2D of batch k+1 under the kernels of batch k; PCIe-inclusive, never `value`), "ragged" = sub-run 2b.
+sortmardup ("sortmardup", Mrecords/s): BASELINE.json configs[3], ONE 200M-record data set; at N > 1 it is routed into N
+  coordinate shards (records by coordinate, templates by record-1 5' end, indicator marks to the owning shard).
 """
 import argparse
 import ctypes
@@ -211,17 +217,54 @@ def smithwaterman_leg(pkg, synth, args, rank, local_rank):
     return out
 
 
+def timed_resident(eng, batch, steps, warmup, barrier):
+    """W untimed + K timed runs of a resident batch, bracketed by barrier + synchronize.  HIP events are
+    recorded on the kernel's own stream around every launch of every run; batch.stats() after the
+    final sync averages the timed runs (the warmup runs are dropped by a stats() call before them)."""
+    for _ in range(warmup):
+        batch.run()
+    eng.sync()
+    batch.stats()                      # forget the warmup runs' events
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run()
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    return dt, batch.stats()
+
+
+def pairhmm_rooflines(st, traffic):
+    ms_dom = st["ms_f32_dominant"]
+    alg_bytes = st["dominant_alg_bytes"]
+    achieved = alg_bytes / (ms_dom * 1e-3) / 1e9
+    valu = 12.0 * st["dominant_cells"] / (ms_dom * 1e-3) / 1e12
+    return ({"bound": "hbm", "limiter": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "traffic": traffic, "traffic_source": "offline rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in this run" if traffic else None,
+             "kernel": st["dominant_kernel"], "kernel_ms": ms_dom, "kernel_ms_source": f"HIP events on the compute stream around every launch inside the timed loop, mean of {st['n_runs_timed']} runs",
+             "step_kernels_ms": st["ms_f32"] + st["ms_f64"], "alg_bytes_per_launch": alg_bytes,
+             "note": "5R+H+4 algorithmic bytes per test case (SURVEY.md 8d); the kernel is fp32-VALU-issue bound, not HBM bound -- see valu"},
+            {"achieved": valu, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu / VALU_FP32_PEAK_TFLOPS,
+             "kernel_gcups": st["dominant_cells"] / (ms_dom * 1e-3) / 1e9, "note": "12 flop per cell (SURVEY.md 8d) against the fp32 vector peak"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=1 << 20, help="test cases per GPU")
+    ap.add_argument("--pairs", type=int, default=0, help="test cases per GPU (default: 1M at one GPU = BASELINE configs[1]; "
+                                                         "--total-pairs / N at N GPUs = configs[2])")
+    ap.add_argument("--total-pairs", type=int, default=64 << 20, help="configs[2]: test cases of the ONE stream the N ranks share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sort-records", type=int, default=200_000_000,
-                    help="records per GPU for the sortmardup leg (BASELINE.json configs[3]); 0 disables it")
+                    help="records of the sortmardup leg (BASELINE.json configs[3]; ONE data set, sharded over the ranks); 0 disables it")
     ap.add_argument("--sort-steps", type=int, default=5)
     ap.add_argument("--sw-pairs", type=int, default=20000, help="Smith-Waterman pairs (row F4 leg; 0 skips it)")
+    ap.add_argument("--queue-lanes", type=int, default=0, help="host lanes of the work queue (default: min(8, cores / ranks))")
+    ap.add_argument("--no-ragged", action="store_true", help="skip sub-run 2b (ragged lengths)")
+    ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[4]: PairHMM queue and sort/mark-duplicate pipeline co-resident")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,76 +288,99 @@ def main():
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
-    seed = 0x5EED0002 + 0x1000 * rank                  # every rank owns its own shard of test cases
-    d = synth.gen_pairhmm_pairs(args.pairs, seed)      # configs[1], sub-run 2a: fixed R=128, H=256
-    eng = pkg.PairHMMEngine(local_rank, flags=pkg.pairhmm.TIMING)
-    t0 = time.perf_counter()
-    batch = eng.batch(d)                               # bins + uploads: resident in HBM from here on
-    upload_s = time.perf_counter() - t0
+    shard = importlib.import_module(PKG + ".shard")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(local_rank)
-        eng.sync()
 
-    for _ in range(args.warmup):
-        batch.run()
-    barrier()
+    def max_over_ranks(x):
+        return shard.max_over_ranks(x, dist, f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+
+    # ---- workload: N = 1 -> BASELINE configs[1] (1M test cases, sub-run 2a); N > 1 -> configs[2]: ONE stream of
+    # --total-pairs test cases (2a distribution, seed 0x5EED0003), rank r owns test cases shard_bounds(total, r, N)
+    if world == 1:
+        seed, total = 0x5EED0002, args.pairs or (1 << 20)
+        lo, hi = 0, total
+        what = f"BASELINE.json configs[1], sub-run 2a: {total} synthetic read x haplotype test cases, read 128 x hap 256, fp32 + fp64 re-run of results < 1e-28"
+    else:
+        seed, total = 0x5EED0003, (args.pairs * world if args.pairs else args.total_pairs)
+        lo, hi = shard.shard_bounds(total, rank, world)
+        what = (f"BASELINE.json configs[2]: ONE stream of {total} synthetic test cases (read 128 x hap 256, seed 0x5EED0003) split over {world} ranks "
+                f"({hi - lo} per GPU), fp32 + fp64 re-run; value = every rank's shard resident in HBM; 'queue' = the same shard streamed from host "
+                "memory through the host work queue (65536-test-case batches, PCIe-inclusive)")
+    d = synth.gen_pairhmm_pairs_fast(hi - lo, seed, first_pair=lo)      # 2a: fixed R=128, H=256
+    eng = pkg.PairHMMEngine(local_rank, flags=pkg.pairhmm.TIMING)
     t0 = time.perf_counter()
-    ms_dom = 0.0
-    for _ in range(args.steps):
-        batch.run()
-        # HIP events recorded on the kernel's own stream, read back after the step completes
+    batch = eng.batch(d)                               # bins + uploads: resident in HBM from here on
     eng.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    st = batch.stats()                                  # events of the last step
-    ms_dom = st["ms_f32_dominant"]
-    # average dominant-kernel duration over a few extra (untimed) steps, events read per step
-    durs = []
-    for _ in range(min(args.steps, 10)):
-        batch.run()
-        durs.append(batch.stats()["ms_f32_dominant"])
-    ms_dom = float(np.mean(durs))
+    upload_s = time.perf_counter() - t0
+    dt, st = timed_resident(eng, batch, args.steps, args.warmup, barrier)
+    tmax = max_over_ranks(dt)
+    value = total * 128 * 256 * args.steps / tmax / 1e9    # every test case of the stream is 128 x 256 cells
+    batch.close()
 
-    tmax = dt
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax = float(t.item())
-    cells_per_step_all = d["cells"] * world             # every rank holds an equal-size shard
-    value = cells_per_step_all * args.steps / tmax / 1e9
-
+    line = None
     if rank == 0:
-        alg_bytes = st["dominant_alg_bytes"]
-        achieved = alg_bytes / (ms_dom * 1e-3) / 1e9
+        roof, valu = pairhmm_rooflines(st, measured_traffic(st["dominant_kernel"]) if hi - lo == (1 << 20) else None)
         line = {
             "metric": "PairHMM GCUPS", "value": value, "unit": "GCUPS", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": tmax / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1], sub-run 2a: 1M synthetic read x haplotype "
-                                   "test cases per GPU, read 128 x hap 256, fp32 + fp64 re-run of results < 1e-28",
-                       "pairs_per_gpu": args.pairs, "read_len": 128, "hap_len": 256, "seed": hex(seed),
+            "config": {"workload": what, "pairs_total": total, "pairs_per_gpu": hi - lo, "read_len": 128, "hap_len": 256, "seed": hex(seed),
                        "rerun_f64_per_step": st["n_rerun_f64"], "parallelism": f"shard{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(st["dominant_kernel"]) if args.pairs == (1 << 20) else None,
-                         "kernel": st["dominant_kernel"], "kernel_ms": ms_dom,
-                         "alg_bytes_per_launch": alg_bytes,
-                         "note": "5R+H+4 algorithmic bytes per test case (SURVEY.md 8d); the kernel is "
-                                 "fp32-VALU-issue bound, not HBM bound -- see valu"},
-            "valu": {"achieved": 12.0 * st["dominant_cells"] / (ms_dom * 1e-3) / 1e12,
-                     "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": 12.0 * st["dominant_cells"] / (ms_dom * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
-                     "kernel_gcups": st["dominant_cells"] / (ms_dom * 1e-3) / 1e9,
-                     "note": "12 flop per cell (SURVEY.md 8d) against the fp32 vector peak"},
-            "upload_s": upload_s,
+            "roofline": roof, "valu": valu, "upload_s": upload_s,
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(synth, 1 << 18, seed)
-    batch.close()
+
+    # ---- the same shard through the host work queue: host buffers in, results in host memory out (PCIe-inclusive;
+    # never `value`).  Lanes pack / upload batch k+1 while the kernels of batch k run.
+    lanes = args.queue_lanes or max(2, min(8, host_cores() // world))      # the ranks of a node share its cores
+    q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
+    prepared = pkg.pairhmm.make_input(d)
+    n_local = hi - lo
+    q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared)      # warm-up: pinned slabs are allocated on first use
+    barrier()
+    t0 = time.perf_counter()
+    qout = q.run(d, prepared=prepared)
+    barrier()
+    qdt = max_over_ranks(time.perf_counter() - t0)
+    qst = q.stats()
+    q.close()
+    if rank == 0:
+        line["queue"] = {"value": total * 128 * 256 / qdt / 1e9, "unit": "GCUPS", "seconds": qdt, "pcie_inclusive": True,
+                         "lanes_per_gpu": lanes, "depth": 2, "batch_pairs": 65536, "batches_per_gpu": qst["n_batches"],
+                         "h2d_GBps_per_gpu": qst["bytes_h2d"] / qst["seconds"] / 1e9, "pack_s_per_lane": qst["pack_seconds"] / lanes,
+                         "wait_s_per_lane": qst["wait_seconds"] / lanes,
+                         "note": "one pass of the host work queue over this rank's shard: pack (gather + bin) -> pinned slab -> H2D -> kernels "
+                                 "-> D2H, results in host memory; bounded by the PCIe link at 900 bytes per 128x256 test case"}
+        # the streamed results are the resident batch's results
+        chk = eng.compute(pkg.pairhmm.pack_batch(d, n_local - 4096, n_local))
+        line["queue"]["identical_to_single_call"] = bool(np.array_equal(chk, qout[n_local - 4096:]))
+    del qout
+
+    # ---- sub-run 2b: ragged lengths R in [32,128], H in [64,256]
+    if not args.no_ragged:
+        n2 = hi - lo if world == 1 else min(hi - lo, 1 << 20)
+        d2 = synth.gen_pairhmm_pairs_fast(n2, 0x5EED0002 + 0x100 * rank, r_range=(32, 128), h_range=(64, 256))
+        b2 = eng.batch(d2)
+        dt2, st2 = timed_resident(eng, b2, args.steps, args.warmup, barrier)
+        t2 = max_over_ranks(dt2)
+        b2.close()
+        if rank == 0:
+            r2, v2 = pairhmm_rooflines(st2, None)
+            line["ragged"] = {"metric": "PairHMM GCUPS, sub-run 2b", "value": d2["cells"] * world * args.steps / t2 / 1e9, "unit": "GCUPS",
+                              "ms_per_step": t2 / args.steps * 1e3, "scaling": "weak",
+                              "config": {"workload": f"SURVEY.md 8d config 2b: {n2} test cases per GPU, read U[32,128] x hap U[64,256], resident",
+                                         "cells_per_gpu": d2["cells"], "launches_f32": st2["n_launches_f32"], "rerun_f64_per_step": st2["n_rerun_f64"]},
+                              "roofline": r2, "valu": v2,
+                              "valu_all_kernels": {"frac": 12.0 * d2["cells"] / (st2["ms_f32"] * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                                                   "note": "all fp32 launches of a step (one per read-length class), 12 flop per cell"}}
+        del d2
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(synth, 1 << 18, seed)
+    del d, prepared
     eng.close()
 
     # ---- second half of BASELINE.json's metric: sortmardup Mrecords/s (configs[3]) ------------

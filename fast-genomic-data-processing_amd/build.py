@@ -17,11 +17,26 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-flush-den
          "-Wall", "-Wno-unused-function"]
 
 
+SYNTH_LIB = os.path.join(HERE, "libmgx_synth.so")     # threaded workload generators (bench / test support, not the product)
+SYNTH_SRC = os.path.join(CSRC, "synth", "synth_gen.cpp")
+
+
+def build_synth(force=False, verbose=True):
+    if not force and os.path.exists(SYNTH_LIB) and os.path.getmtime(SYNTH_LIB) >= os.path.getmtime(SYNTH_SRC):
+        return SYNTH_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-o", SYNTH_LIB, SYNTH_SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return SYNTH_LIB
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
 def build(force=False, verbose=True):
+    build_synth(force, verbose)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = [os.path.abspath(__file__)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))] + [
         os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]

@@ -15,14 +15,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "../../include/mgx_pairhmm.h"
 #include "mgx_common.h"
 #include "mgx_tables.h"
+#include "pairhmm_pack.h"
 #include "pairhmm_kernels.hip.inc"
 
 using mgx::set_error;
@@ -54,17 +58,18 @@ namespace {
 // Slabs are recycled through the context, so a stream of region-sized batches does no hipMalloc.
 struct Slab {
     uint8_t* dev = nullptr;
-    uint8_t* pin = nullptr;
-    size_t cap = 0;
+    uint8_t* pin = nullptr;     // mirrors the first pin_cap bytes only: inputs and results, never device scratch
+    size_t cap = 0, pin_cap = 0;
 };
 constexpr size_t kStageLimit = 256u << 20;
+constexpr size_t kMaxEventSets = 64;       // runs whose kernel durations a timed batch remembers
 constexpr size_t kMinSlab = 1u << 20;
 }  // namespace
 
 struct mgx_pairhmm {
     int device = 0;
     unsigned flags = 0;
-    hipStream_t compute = nullptr, copy = nullptr;
+    hipStream_t compute = nullptr, copy = nullptr, d2h = nullptr;   // kernels | uploads | result downloads
     float* d_ph2pr_f = nullptr; float* d_mm_f = nullptr; float* d_div3_f = nullptr; float* d_ratio_f = nullptr;
     double* d_ph2pr_d = nullptr; double* d_mm_d = nullptr; double* d_div3_d = nullptr; double* d_ratio_d = nullptr;
     float log10_initial_f = 0; double log10_initial_d = 0;
@@ -96,13 +101,23 @@ struct mgx_pairhmm_batch {
     size_t o_keep = 0;
     double log10_rate = 0, max_err = 0;
     hipEvent_t uploaded = nullptr;
-    // timing
-    std::vector<hipEvent_t> ev;    // 4 per bin: f32 start/stop, f64 start/stop
+    // timing: a ring of event sets, one set per run (4 per bin: f32 start/stop, f64 start/stop), so that
+    // every run of a timed loop is measured and batch_stats can average them after the final sync
+    std::vector<hipEvent_t> ev;
+    uint32_t ev_sets = 0;          // sets allocated
+    uint32_t runs_timed = 0;       // runs recorded since the last batch_stats
+    hipEvent_t done = nullptr;     // recorded on the compute stream behind the last kernel of a run
     bool ran = false;
     mgx_pairhmm_stats_t stats{};
 };
 
 namespace {
+
+using BatchPtr = std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)>;
+BatchPtr new_batch() {
+    // (on an error path the slab is freed, not pooled: destroy is called without the context)
+    return BatchPtr(new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+}
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
@@ -175,23 +190,27 @@ void merge_small_bins(uint64_t (&count)[kBins], int (&remap)[kBins]) {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-int acquire_slab(mgx_pairhmm* c, size_t bytes, bool want_pinned, Slab* out) {
+int acquire_slab(mgx_pairhmm* c, size_t bytes, size_t pin_bytes, Slab* out) {
     int best = -1;
     for (size_t i = 0; i < c->free_slabs.size(); ++i) {
         const Slab& f = c->free_slabs[i];
-        if (f.cap >= bytes && (!want_pinned || f.pin) && (best < 0 || f.cap < c->free_slabs[best].cap)) best = (int)i;
+        if (f.cap >= bytes && f.pin_cap >= pin_bytes && (best < 0 || f.cap < c->free_slabs[best].cap)) best = (int)i;
     }
     if (best >= 0) { *out = c->free_slabs[best]; c->free_slabs.erase(c->free_slabs.begin() + best); return 0; }
-    size_t cap = kMinSlab;
-    while (cap < bytes) cap *= 2;
-    if (cap > bytes + (bytes >> 2) && bytes > (64u << 20)) cap = align_up(bytes, 1u << 20);   // no 2x waste on big batches
+    auto round = [](size_t want) {
+        size_t cap = kMinSlab;
+        while (cap < want) cap *= 2;
+        if (cap > want + (want >> 2) && want > (64u << 20)) cap = align_up(want, 1u << 20);   // no 2x waste on big batches
+        return cap;
+    };
     Slab sl;
-    sl.cap = cap;
-    HIP_TRY(hipMalloc((void**)&sl.dev, cap));
-    if (want_pinned) {
-        if (hipHostMalloc((void**)&sl.pin, cap, hipHostMallocDefault) != hipSuccess) {
+    sl.cap = round(bytes);
+    HIP_TRY(hipMalloc((void**)&sl.dev, sl.cap));
+    if (pin_bytes) {
+        sl.pin_cap = std::min(sl.cap, round(pin_bytes));
+        if (hipHostMalloc((void**)&sl.pin, sl.pin_cap, hipHostMallocDefault) != hipSuccess) {
             (void)hipFree(sl.dev);
-            set_error("hipHostMalloc of %zu bytes failed", cap);
+            set_error("hipHostMalloc of %zu bytes failed", sl.pin_cap);
             return -ENOMEM;
         }
     }
@@ -211,6 +230,10 @@ int validate(const mgx_pairhmm_input_t* in) {
     if (!in->read_off || !in->hap_off || !in->bases || !in->qual || !in->ins || !in->del ||
         !in->gcp || !in->hap_bases || (!in->pair_read != !in->pair_hap)) {
         set_error("a required input array is NULL");
+        return -EINVAL;
+    }
+    if (!in->pair_read && (in->n_reads == 0 || in->n_haps == 0)) {
+        set_error("%llu test cases without pair arrays and without reads or haplotypes", (unsigned long long)in->n_pairs);
         return -EINVAL;
     }
     if (in->n_pairs > 0xFFFFFFF0ull) { set_error("more than 2^32 test cases in one batch"); return -E2BIG; }
@@ -275,6 +298,7 @@ int mgx_pairhmm_create(int device, unsigned flags, mgx_pairhmm_t** out) {
         }
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
     const auto& tf = mgx::tables<float>();
     const auto& td = mgx::tables<double>();
     int rc;
@@ -302,6 +326,7 @@ void mgx_pairhmm_destroy(mgx_pairhmm_t* c) {
     for (auto& sl : c->free_slabs) { (void)hipFree(sl.dev); if (sl.pin) (void)hipHostFree(sl.pin); }
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
+    if (c->d2h) (void)hipStreamDestroy(c->d2h);
     delete c;
 }
 
@@ -309,12 +334,15 @@ void mgx_pairhmm_batch_destroy(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     if (!b) return;
     if (c) {
         (void)hipSetDevice(c->device);
-        // the slab goes back to the pool: nothing may still be reading or writing it
-        (void)hipStreamSynchronize(c->copy);
-        (void)hipStreamSynchronize(c->compute);
+        // the slab goes back to the pool: nothing may still be reading or writing it.  Only THIS batch's
+        // work is waited for (its last run, or its upload if it never ran; result downloads are
+        // synchronous), so retiring one batch does not stall on the batches queued behind it.
+        if (b->done) (void)hipEventSynchronize(b->done);
+        else if (b->uploaded) (void)hipEventSynchronize(b->uploaded);
     }
     release_slab(c, b->slab);
     if (b->uploaded) (void)hipEventDestroy(b->uploaded);
+    if (b->done) (void)hipEventDestroy(b->done);
     for (auto e : b->ev) (void)hipEventDestroy(e);
     delete b;
 }
@@ -372,15 +400,15 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
     const size_t o_mapq = off;  off = align_up(off + (model ? nr : 0));
     const size_t o_rlen = off;  off = align_up(off + (model ? nr * sizeof(uint64_t) : 0));
     b->in_bytes = off;
-    const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
     b->o_out = off;             off = align_up(off + n * sizeof(double));
     b->o_used = off;            off = align_up(off + n);
     b->o_keep = off;            off = align_up(off + (model ? nr : 0));
     b->result_bytes = off - b->o_out;
+    const size_t pin_bytes = off;              // the pinned mirror covers the inputs and the results only
+    const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
     const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
-    // the pinned mirror only has to cover the inputs and the results
-    if ((rc = acquire_slab(c, off, true, &b->slab))) return rc;
+    if ((rc = acquire_slab(c, off, pin_bytes, &b->slab))) return rc;
     uint8_t* dv = b->slab.dev; uint8_t* pin = b->slab.pin;
     b->d_jobs = (Job*)(dv + o_jobs);
     b->d_bases = dv + o_bases; b->d_qual = dv + o_qual; b->d_ins = dv + o_ins; b->d_del = dv + o_del;
@@ -535,14 +563,15 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
     const size_t o_roff = off;  off = align_up(off + (model ? nr * sizeof(uint32_t) : 0));
     const size_t o_rnh = off;   off = align_up(off + (model ? nr * sizeof(uint32_t) : 0));
     b->in_bytes = off;
-    const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
     b->o_out = off;             off = align_up(off + n * sizeof(double));
     b->o_used = off;            off = align_up(off + n);
     b->o_keep = off;            off = align_up(off + (model ? nr : 0));
     b->result_bytes = off - b->o_out;
+    const size_t pin_bytes = off;              // the pinned mirror covers the inputs and the results only
+    const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
     const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
-    if ((rc = acquire_slab(c, off, true, &b->slab))) return rc;
+    if ((rc = acquire_slab(c, off, pin_bytes, &b->slab))) return rc;
     uint8_t* dv = b->slab.dev; uint8_t* pin = b->slab.pin;
     b->d_jobs = (Job*)(dv + o_jobs);
     b->d_bases = dv + o_bases; b->d_qual = dv + o_qual; b->d_ins = dv + o_ins; b->d_del = dv + o_del;
@@ -650,27 +679,19 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
 
 }  // namespace
 
-int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
-                             mgx_pairhmm_batch_t** out) {
-    if (!c || !out) { set_error("ctx/out is NULL"); return -EINVAL; }
-    *out = nullptr;
-    int rc = validate(in);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
-        new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
-    // (on an error path the slab is freed, not pooled: destroy is called without the context)
-    if (!b) return -ENOMEM;
-    if (!in->pair_read && !in->pair_hap && in->n_reads && in->n_haps) {      // cross-product form
-        if ((rc = create_cross(c, in, b.get()))) return rc;
-        if (c->flags & MGX_PAIRHMM_TIMING) {
-            b->ev.resize(b->bins.size() * 4);
-            for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
-        }
-        *out = b.release();
-        return 0;
-    }
-    const uint64_t n = in->n_pairs;
+namespace {
+
+// Pair-list batch.  plan == nullptr: the test cases of `in` with its read / haplotype arrays copied as
+// they are.  plan != nullptr: test cases [plan->lo, plan->hi) of `in`, only the sequences they reference
+// (gathered by the packer, pairhmm_pack.h) -- the form the host work queue uploads.
+int create_pairs(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const mgx::PackPlan* plan, mgx_pairhmm_batch* b) {
+    const uint64_t n = plan ? plan->hi - plan->lo : in->n_pairs;
+    const uint32_t* pr = plan ? plan->pair_read.data() : in->pair_read;
+    const uint32_t* ph = plan ? plan->pair_hap.data() : in->pair_hap;
+    const uint64_t* roff = plan ? plan->roff.data() : in->read_off;
+    const uint64_t* hoff = plan ? plan->hoff.data() : in->hap_off;
+    const uint64_t n_reads = plan ? plan->lread.size() : in->n_reads, n_haps = plan ? plan->lhap.size() : in->n_haps;
+    int rc;
     b->n_pairs = n;
     b->stats.n_pairs = n;
 
@@ -679,10 +700,10 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
     uint64_t count[kBins] = {0};
     uint32_t max_h = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        const uint32_t r = in->pair_read[i], h = in->pair_hap[i];
-        if (r >= in->n_reads || h >= in->n_haps) { set_error("test case %llu: index out of range", (unsigned long long)i); return -EINVAL; }
-        const uint64_t R = in->read_off[r + 1] - in->read_off[r];
-        const uint64_t H = in->hap_off[h + 1] - in->hap_off[h];
+        const uint32_t r = pr[i], h = ph[i];
+        if (r >= n_reads || h >= n_haps) { set_error("test case %llu: index out of range", (unsigned long long)i); return -EINVAL; }
+        const uint64_t R = roff[r + 1] - roff[r];
+        const uint64_t H = hoff[h + 1] - hoff[h];
         if (R == 0 || H == 0) { set_error("test case %llu: empty read or haplotype", (unsigned long long)i); return -EINVAL; }
         int G, RPL;
         shape_of((uint32_t)std::min<uint64_t>(R, 0xFFFFFFFFull), &G, &RPL);
@@ -705,8 +726,8 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
     }
     // ---- one slab for everything; layout decided before the jobs are written so that they can be
     //      built directly in the pinned mirror
-    const uint64_t read_bytes = in->read_off[in->n_reads];
-    const uint64_t hap_bytes = in->hap_off[in->n_haps];
+    const uint64_t read_bytes = roff[n_reads];
+    const uint64_t hap_bytes = hoff[n_haps];
     size_t off = 0;
     const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
     const size_t o_bases = off; off = align_up(off + read_bytes);
@@ -721,8 +742,8 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
     b->result_bytes = off - b->o_out;
     const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
-    const bool staged = off <= kStageLimit;
-    if ((rc = acquire_slab(c, off, staged, &b->slab))) return rc;
+    const bool staged = plan || o_rlist <= kStageLimit;
+    if ((rc = acquire_slab(c, off, staged ? o_rlist : 0, &b->slab))) return rc;
     uint8_t* dv = b->slab.dev;
     b->d_jobs = (Job*)(dv + o_jobs);
     b->d_bases = dv + o_bases; b->d_qual = dv + o_qual; b->d_ins = dv + o_ins; b->d_del = dv + o_del;
@@ -739,19 +760,19 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
         std::vector<std::vector<uint32_t>> hist(kBins);
         for (int k = 0; k < kBins; ++k) if (count[k]) hist[k].assign((size_t)max_h + 2, 0);
         for (uint64_t i = 0; i < n; ++i) {
-            const uint32_t h = in->pair_hap[i];
-            const uint32_t H = (uint32_t)(in->hap_off[h + 1] - in->hap_off[h]);
+            const uint32_t h = ph[i];
+            const uint32_t H = (uint32_t)(hoff[h + 1] - hoff[h]);
             hist[bin_of[i]][H + 1]++;
         }
         for (int k = 0; k < kBins; ++k)
             for (size_t x = 1; x < hist[k].size(); ++x) hist[k][x] += hist[k][x - 1];
         for (uint64_t i = 0; i < n; ++i) {
-            const uint32_t r = in->pair_read[i], h = in->pair_hap[i];
-            const uint32_t R = (uint32_t)(in->read_off[r + 1] - in->read_off[r]);
-            const uint32_t H = (uint32_t)(in->hap_off[h + 1] - in->hap_off[h]);
+            const uint32_t r = pr[i], h = ph[i];
+            const uint32_t R = (uint32_t)(roff[r + 1] - roff[r]);
+            const uint32_t H = (uint32_t)(hoff[h + 1] - hoff[h]);
             const int k = (int)bin_of[i];
             Job& jb = jobs[bin_start[k] + hist[k][H]++];
-            jb.read_off = in->read_off[r]; jb.hap_off = in->hap_off[h];
+            jb.read_off = roff[r]; jb.hap_off = hoff[h];
             jb.R = R; jb.H = H; jb.pair = (uint32_t)i; jb.pad_ = 0;
         }
         for (int k = 0; k < kBins; ++k) {
@@ -774,9 +795,13 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
     hipStream_t s = c->copy;
     if (staged) {
         uint8_t* pin = b->slab.pin;
-        memcpy(pin + o_bases, in->bases, read_bytes); memcpy(pin + o_qual, in->qual, read_bytes);
-        memcpy(pin + o_ins, in->ins, read_bytes);     memcpy(pin + o_del, in->del, read_bytes);
-        memcpy(pin + o_gcp, in->gcp, read_bytes);     memcpy(pin + o_hap, in->hap_bases, hap_bytes);
+        if (plan) {
+            mgx::pack_copy(in, *plan, pin + o_bases, pin + o_qual, pin + o_ins, pin + o_del, pin + o_gcp, pin + o_hap);
+        } else {
+            memcpy(pin + o_bases, in->bases, read_bytes); memcpy(pin + o_qual, in->qual, read_bytes);
+            memcpy(pin + o_ins, in->ins, read_bytes);     memcpy(pin + o_del, in->del, read_bytes);
+            memcpy(pin + o_gcp, in->gcp, read_bytes);     memcpy(pin + o_hap, in->hap_bases, hap_bytes);
+        }
         HIP_TRY(hipMemcpyAsync(dv, pin, b->in_bytes, hipMemcpyHostToDevice, s));
     } else {
         HIP_TRY(hipMemcpyAsync(b->d_jobs, jobs, n * sizeof(Job), hipMemcpyHostToDevice, s));
@@ -791,10 +816,23 @@ int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
     }
     HIP_TRY(hipEventCreateWithFlags(&b->uploaded, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->uploaded, s));       // batch_run makes the compute stream wait on this
-    if (c->flags & MGX_PAIRHMM_TIMING) {
-        b->ev.resize(b->bins.size() * 4);
-        for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
-    }
+    return 0;
+}
+
+}  // namespace
+
+int mgx_pairhmm_batch_create(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in,
+                             mgx_pairhmm_batch_t** out) {
+    if (!c || !out) { set_error("ctx/out is NULL"); return -EINVAL; }
+    *out = nullptr;
+    int rc = validate(in);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    BatchPtr b = new_batch();
+    if (!b) return -ENOMEM;
+    if (!in->pair_read && !in->pair_hap && in->n_reads && in->n_haps) rc = create_cross(c, in, b.get());   // cross-product form
+    else rc = create_pairs(c, in, nullptr, b.get());
+    if (rc) return rc;
     *out = b.release();
     return 0;
 }
@@ -804,8 +842,18 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     HIP_TRY(hipSetDevice(c->device));
     if (b->n_pairs == 0) { b->ran = true; return 0; }
     hipStream_t s = c->compute;
-    const bool timing = (c->flags & MGX_PAIRHMM_TIMING) != 0;
+    const bool timing = (c->flags & MGX_PAIRHMM_TIMING) != 0 && !b->bins.empty();
     const bool force_f64 = (c->flags & MGX_PAIRHMM_FORCE_DOUBLE) != 0;
+    hipEvent_t* ev = nullptr;                  // this run's event set
+    if (timing) {
+        if (b->ev.empty()) {                   // whichever entry point made the batch: allocated on first use
+            const size_t per = b->bins.size() * 4;
+            b->ev_sets = (uint32_t)std::max<size_t>(1, std::min<size_t>(kMaxEventSets, 1024 / per));
+            b->ev.resize(per * b->ev_sets);
+            for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
+        }
+        ev = b->ev.data() + (size_t)(b->runs_timed % b->ev_sets) * b->bins.size() * 4;
+    }
     if (b->uploaded) HIP_TRY(hipStreamWaitEvent(s, b->uploaded, 0));
     HIP_TRY(hipMemsetAsync(b->d_rerun_count, 0, 64 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(b->d_used, 0, b->n_pairs, s));
@@ -826,9 +874,9 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f; a.ph2pr_div3 = c->d_div3_f; a.gap_ratio = c->d_ratio_f;
             KernelFn f = pick_kernel<float>(bin.G, bin.RPL);
             if (!f) { set_error("no fp32 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
-            if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 0], s));
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 0], s));
             hipLaunchKernelGGL(f, dim3(bin.grid_f32), dim3(bin.block), lds_bytes(bin, true), s, a);
-            if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 1], s));
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 1], s));
         }
         {
             a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d; a.ph2pr_div3 = c->d_div3_d; a.gap_ratio = c->d_ratio_d;
@@ -836,9 +884,9 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             else { a.job_list = b->d_rerun_list + bin.job_begin; a.n_dyn = b->d_rerun_count + k; a.n_static = 0; }
             KernelFn f = pick_kernel<double>(bin.Gd, bin.RPLd);
             if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", bin.Gd, bin.RPLd); return -ENOSYS; }
-            if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 2], s));
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 2], s));
             hipLaunchKernelGGL(f, dim3(force_f64 ? bin.grid_f64_all : bin.grid_f64), dim3(bin.block), lds_bytes(bin, false), s, a);
-            if (timing) HIP_TRY(hipEventRecord(b->ev[4 * k + 3], s));
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 3], s));
         }
     }
     if (b->has_model && b->d_row_off)
@@ -848,6 +896,9 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         hipLaunchKernelGGL(pairhmm_normalize_filter, dim3((b->n_reads + 3) / 4), dim3(256), 0, s, b->d_out, b->d_read_len,
                            b->n_reads, b->n_haps, b->log10_rate, b->max_err, b->d_keep);
     HIP_TRY(hipGetLastError());
+    if (timing) b->runs_timed++;
+    if (!b->done) HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->done, s));
     b->ran = true;
     return 0;
 }
@@ -876,26 +927,37 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, mgx_pairhm
     st.ms_f32 = st.ms_f64 = st.ms_f32_dominant = 0;
     st.dominant_cells = st.dominant_alg_bytes = 0;
     st.dominant_kernel[0] = 0;
-    if ((c->flags & MGX_PAIRHMM_TIMING) && b->ran && !b->ev.empty()) {
-        uint64_t best_cells = 0;
-        for (size_t k = 0; k < b->bins.size(); ++k) {
-            float ms = 0;
-            if (!force_f64) {
-                HIP_TRY(hipEventElapsedTime(&ms, b->ev[4 * k + 0], b->ev[4 * k + 1]));
-                st.ms_f32 += ms;
-                if (b->bins[k].cells >= best_cells) {
-                    best_cells = b->bins[k].cells;
-                    st.ms_f32_dominant = ms;
-                    st.dominant_cells = b->bins[k].cells;
-                    st.dominant_alg_bytes = b->bins[k].alg_bytes;
-                    snprintf(st.dominant_kernel, sizeof st.dominant_kernel,
-                             "pairhmm_fwd<float, %d, %d>", b->bins[k].G, b->bins[k].RPL);
+    st.n_runs_timed = 0;
+    if ((c->flags & MGX_PAIRHMM_TIMING) && b->ran && !b->ev.empty() && b->runs_timed) {
+        // mean over the runs recorded since the previous call (the ring keeps the last ev_sets of them)
+        const uint32_t n_sets = std::min(b->runs_timed, b->ev_sets);
+        size_t dom = 0;
+        for (size_t k = 0; k < b->bins.size(); ++k) if (b->bins[k].cells >= b->bins[dom].cells) dom = k;
+        double f32 = 0, f64 = 0, domms = 0;
+        for (uint32_t q = 0; q < n_sets; ++q) {
+            const uint32_t set = (b->runs_timed - 1 - q) % b->ev_sets;
+            hipEvent_t* ev = b->ev.data() + (size_t)set * b->bins.size() * 4;
+            for (size_t k = 0; k < b->bins.size(); ++k) {
+                float ms = 0;
+                if (!force_f64) {
+                    HIP_TRY(hipEventElapsedTime(&ms, ev[4 * k + 0], ev[4 * k + 1]));
+                    f32 += ms;
+                    if (k == dom) domms += ms;
                 }
+                float ms2 = 0;
+                HIP_TRY(hipEventElapsedTime(&ms2, ev[4 * k + 2], ev[4 * k + 3]));
+                f64 += ms2;
             }
-            float ms2 = 0;
-            HIP_TRY(hipEventElapsedTime(&ms2, b->ev[4 * k + 2], b->ev[4 * k + 3]));
-            st.ms_f64 += ms2;
         }
+        st.n_runs_timed = n_sets;
+        st.ms_f32 = (float)(f32 / n_sets); st.ms_f64 = (float)(f64 / n_sets);
+        if (!force_f64) {
+            st.ms_f32_dominant = (float)(domms / n_sets);
+            st.dominant_cells = b->bins[dom].cells;
+            st.dominant_alg_bytes = b->bins[dom].alg_bytes;
+            snprintf(st.dominant_kernel, sizeof st.dominant_kernel, "pairhmm_fwd<float, %d, %d>", b->bins[dom].G, b->bins[dom].RPL);
+        }
+        b->runs_timed = 0;
     }
     *out = st;
     return 0;
@@ -908,18 +970,22 @@ int mgx_pairhmm_batch_results(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, double* 
     HIP_TRY(hipSetDevice(c->device));
     if (b->n_pairs == 0) return 0;
     if (!out_log10) { set_error("out_log10 is NULL"); return -EINVAL; }
+    // downloads run on their own stream behind this batch's last kernel, so the results of batch k do not
+    // queue behind the kernels of batch k+1 that were enqueued in the meantime
+    hipStream_t s = c->d2h;
+    if (b->done) HIP_TRY(hipStreamWaitEvent(s, b->done, 0));
     if (b->slab.pin) {
         uint8_t* pin = b->slab.pin + b->o_out;
         const size_t bytes = used_f64 ? b->result_bytes : b->n_pairs * sizeof(double);
-        HIP_TRY(hipMemcpyAsync(pin, b->d_out, bytes, hipMemcpyDeviceToHost, c->compute));
-        HIP_TRY(hipStreamSynchronize(c->compute));
+        HIP_TRY(hipMemcpyAsync(pin, b->d_out, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
         memcpy(out_log10, pin, b->n_pairs * sizeof(double));
         if (used_f64) memcpy(used_f64, b->slab.pin + b->o_used, b->n_pairs);
         return 0;
     }
-    HIP_TRY(hipMemcpyAsync(out_log10, b->d_out, b->n_pairs * sizeof(double), hipMemcpyDeviceToHost, c->compute));
-    if (used_f64) HIP_TRY(hipMemcpyAsync(used_f64, b->d_used, b->n_pairs, hipMemcpyDeviceToHost, c->compute));
-    HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipMemcpyAsync(out_log10, b->d_out, b->n_pairs * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (used_f64) HIP_TRY(hipMemcpyAsync(used_f64, b->d_used, b->n_pairs, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -940,8 +1006,7 @@ int mgx_pairhmm_region(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const ui
     if (rc) return rc;
     if (in->n_reads == 0 || in->n_haps == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
-        new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+    BatchPtr b = new_batch();
     if (!b) return -ENOMEM;
     if ((rc = create_cross(c, in, b.get(), mapq, model))) return rc;
     mgx_pairhmm_batch* raw = b.release();
@@ -982,8 +1047,7 @@ int mgx_pairhmm_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_
         if (regions[g].n_reads * regions[g].n_haps && !out_log10[g]) { set_error("region %u: output pointer is NULL", g); return -EINVAL; }
     }
     HIP_TRY(hipSetDevice(c->device));
-    std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
-        new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+    BatchPtr b = new_batch();
     if (!b) return -ENOMEM;
     std::vector<uint64_t> base;
     if ((rc = create_cross_multi(c, n_regions, regions, b.get(), &base, mapq, model))) return rc;
@@ -1021,16 +1085,11 @@ int mgx_pairhmm_compute_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_
         if (regions[g].n_reads * regions[g].n_haps && !out_log10[g]) { set_error("region %u: output pointer is NULL", g); return -EINVAL; }
     }
     HIP_TRY(hipSetDevice(c->device));
-    std::unique_ptr<mgx_pairhmm_batch, void (*)(mgx_pairhmm_batch*)> b(
-        new (std::nothrow) mgx_pairhmm_batch, [](mgx_pairhmm_batch* p) { mgx_pairhmm_batch_destroy(nullptr, p); });
+    BatchPtr b = new_batch();
     if (!b) return -ENOMEM;
     std::vector<uint64_t> base;
     if ((rc = create_cross_multi(c, n_regions, regions, b.get(), &base))) return rc;
     if (b->n_pairs == 0) return 0;
-    if (c->flags & MGX_PAIRHMM_TIMING) {
-        b->ev.resize(b->bins.size() * 4);
-        for (auto& e : b->ev) HIP_TRY(hipEventCreate(&e));
-    }
     mgx_pairhmm_batch_t* raw = b.release();
     rc = mgx_pairhmm_batch_run(c, raw);
     std::vector<double> all;
@@ -1039,6 +1098,207 @@ int mgx_pairhmm_compute_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_
     if (rc) return rc;
     for (uint32_t g = 0; g < n_regions; ++g)
         if (base[g + 1] > base[g]) memcpy(out_log10[g], all.data() + base[g], (base[g + 1] - base[g]) * sizeof(double));
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Host work queue (BASELINE.json configs[2]).  The reference's worker threads pull the next active
+// region off one atomic index (deepmutect/Mutect2Cpp-master/src/main.cpp:254) and share the tail of the
+// work at the end (main.cpp:302-315, IntelPairHmm.cc:296-330).  Here the unit pulled is a BATCH of test
+// cases: every lane -- a host thread with its own context, i.e. its own streams and recycled pinned
+// slabs -- takes the next batch index, plans and packs it (pairhmm_pack.h), uploads, launches and moves on
+// to the next one while the device works; a batch's results are fetched when its slot comes round
+// again, `depth` batches later.  Several lanes per device keep the PCIe link busy (one core packs
+// ~10 GB/s, the link takes ~55); lanes of different devices share the same counter, so a faster GPU
+// simply takes more batches.  No collective, no device-to-device traffic.
+// ---------------------------------------------------------------------------------------------
+struct mgx_pairhmm_queue {
+    struct Lane {
+        mgx_pairhmm* ctx = nullptr;
+        uint32_t dev_slot = 0;
+        double pack_s = 0, wait_s = 0;
+        uint64_t batches = 0, bytes_h2d = 0, bytes_d2h = 0, cells = 0;
+    };
+    std::vector<Lane> lanes;
+    uint32_t n_devices = 1, depth = 2, batch_pairs = 65536;
+    mgx_pairhmm_queue_stats_t stats{};
+};
+
+namespace {
+
+struct QueueRun {
+    const mgx_pairhmm_input_t* in = nullptr;
+    uint64_t lo = 0, hi = 0, n_batches = 0;
+    double* out = nullptr;
+    uint8_t* used = nullptr;
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> failed{0};
+    std::mutex err_mu;
+    int rc = 0;
+    std::string err;
+    void fail(int code) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!rc) { rc = code; err = mgx_last_error(); }
+        failed.store(1);
+    }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void queue_lane(mgx_pairhmm_queue* q, mgx_pairhmm_queue::Lane* ln, QueueRun* run) {
+    struct Slot { mgx_pairhmm_batch* b = nullptr; uint64_t lo = 0; };
+    std::vector<Slot> slots(q->depth);
+    mgx::PackPlan plan;
+    mgx_pairhmm* c = ln->ctx;
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", c->device); run->fail(-EIO); return; }
+    auto retire = [&](Slot& sl) {
+        if (!sl.b) return;
+        const double t0 = now_s();
+        if (!run->failed.load()) {
+            const uint64_t at = sl.lo - run->lo;
+            const int rc = mgx_pairhmm_batch_results(c, sl.b, run->out + at, run->used ? run->used + at : nullptr);
+            if (rc) run->fail(rc);
+            ln->bytes_d2h += sl.b->n_pairs * (run->used ? 9 : 8);
+        }
+        mgx_pairhmm_batch_destroy(c, sl.b);
+        sl.b = nullptr;
+        ln->wait_s += now_s() - t0;
+    };
+    size_t turn = 0;
+    while (!run->failed.load()) {
+        const uint64_t k = run->next.fetch_add(1);
+        if (k >= run->n_batches) break;
+        Slot& sl = slots[turn++ % slots.size()];
+        retire(sl);
+        if (run->failed.load()) break;
+        const uint64_t lo = run->lo + k * q->batch_pairs, hi = std::min(run->hi, lo + q->batch_pairs);
+        const double t0 = now_s();
+        const uint64_t bad = mgx::pack_plan(run->in, lo, hi, &plan);
+        if (bad) { set_error("test case %llu: index out of range", (unsigned long long)(lo + bad - 1)); run->fail(-EINVAL); break; }
+        BatchPtr b = new_batch();
+        int rc = b ? create_pairs(c, run->in, &plan, b.get()) : -ENOMEM;
+        ln->pack_s += now_s() - t0;
+        if (!rc) rc = mgx_pairhmm_batch_run(c, b.get());
+        if (rc) { run->fail(rc); break; }
+        ln->batches++; ln->bytes_h2d += b->in_bytes; ln->cells += b->stats.cells;
+        sl.b = b.release(); sl.lo = lo;
+    }
+    for (size_t j = 0; j < slots.size(); ++j) retire(slots[(turn + j) % slots.size()]);    // oldest first
+}
+
+}  // namespace
+
+int mgx_pairhmm_queue_create(const mgx_pairhmm_queue_config_t* cfg, mgx_pairhmm_queue_t** out) {
+    if (!out) { set_error("out is NULL"); return -EINVAL; }
+    *out = nullptr;
+    mgx_pairhmm_queue_config_t d{};
+    if (cfg) d = *cfg;
+    const int dev0 = 0;
+    const uint32_t n_dev = d.n_devices && d.devices ? d.n_devices : 1;
+    if (n_dev > 16) { set_error("at most 16 devices per queue"); return -EINVAL; }
+    const uint32_t lanes = d.lanes_per_device ? d.lanes_per_device : 4;
+    if (lanes > 32) { set_error("at most 32 lanes per device"); return -EINVAL; }
+    std::unique_ptr<mgx_pairhmm_queue> q(new (std::nothrow) mgx_pairhmm_queue);
+    if (!q) return -ENOMEM;
+    q->n_devices = n_dev;
+    q->depth = d.depth ? std::min<uint32_t>(d.depth, 8) : 2;
+    q->batch_pairs = d.batch_pairs ? d.batch_pairs : 65536;
+    for (uint32_t v = 0; v < n_dev; ++v)
+        for (uint32_t l = 0; l < lanes; ++l) {
+            mgx_pairhmm_queue::Lane ln;
+            ln.dev_slot = v;
+            const int rc = mgx_pairhmm_create(d.n_devices && d.devices ? d.devices[v] : dev0, d.flags, &ln.ctx);
+            if (rc) { for (auto& x : q->lanes) mgx_pairhmm_destroy(x.ctx); return rc; }
+            q->lanes.push_back(ln);
+        }
+    *out = q.release();
+    return 0;
+}
+
+void mgx_pairhmm_queue_destroy(mgx_pairhmm_queue_t* q) {
+    if (!q) return;
+    for (auto& ln : q->lanes) mgx_pairhmm_destroy(ln.ctx);
+    delete q;
+}
+
+int mgx_pairhmm_queue_run_range(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_t* in, uint64_t pair_begin, uint64_t pair_end,
+                                double* out_log10, uint8_t* used_f64) {
+    if (!q) { set_error("queue is NULL"); return -EINVAL; }
+    int rc = validate(in);
+    if (rc) return rc;
+    const uint64_t total = mgx::pack_n_pairs(in);
+    if (pair_begin > pair_end || pair_end > total) { set_error("test-case range [%llu, %llu) outside the stream of %llu", (unsigned long long)pair_begin, (unsigned long long)pair_end, (unsigned long long)total); return -EINVAL; }
+    q->stats = mgx_pairhmm_queue_stats_t{};
+    q->stats.n_lanes = (uint32_t)q->lanes.size();
+    if (pair_begin == pair_end) return 0;
+    if (!out_log10) { set_error("out_log10 is NULL"); return -EINVAL; }
+    QueueRun run;
+    run.in = in; run.lo = pair_begin; run.hi = pair_end; run.out = out_log10; run.used = used_f64;
+    run.n_batches = (pair_end - pair_begin + q->batch_pairs - 1) / q->batch_pairs;
+    for (auto& ln : q->lanes) { ln.pack_s = ln.wait_s = 0; ln.batches = ln.bytes_h2d = ln.bytes_d2h = ln.cells = 0; }
+    const double t0 = now_s();
+    const size_t n_thr = (size_t)std::min<uint64_t>(q->lanes.size(), run.n_batches);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < n_thr; ++i) th.emplace_back(queue_lane, q, &q->lanes[i], &run);
+    queue_lane(q, &q->lanes[0], &run);               // the caller's thread is lane 0
+    for (auto& t : th) t.join();
+    q->stats.seconds = now_s() - t0;
+    q->stats.n_pairs = pair_end - pair_begin;
+    q->stats.n_batches = run.n_batches;
+    for (auto& ln : q->lanes) {
+        q->stats.cells += ln.cells; q->stats.bytes_h2d += ln.bytes_h2d; q->stats.bytes_d2h += ln.bytes_d2h;
+        q->stats.pack_seconds += ln.pack_s; q->stats.wait_seconds += ln.wait_s;
+        q->stats.batches_per_device[ln.dev_slot] += ln.batches;
+    }
+    if (run.rc) { set_error("%s", run.err.c_str()); return run.rc; }
+    return 0;
+}
+
+int mgx_pairhmm_queue_run(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_t* in, double* out_log10, uint8_t* used_f64) {
+    if (!in) { set_error("input is NULL"); return -EINVAL; }
+    return mgx_pairhmm_queue_run_range(q, in, 0, mgx::pack_n_pairs(in), out_log10, used_f64);
+}
+
+int mgx_pairhmm_queue_stats(mgx_pairhmm_queue_t* q, mgx_pairhmm_queue_stats_t* out) {
+    if (!q || !out) { set_error("NULL argument"); return -EINVAL; }
+    *out = q->stats;
+    return 0;
+}
+
+// Host-only: test cases [pair_begin, pair_end) of `in` as a self-contained batch laid out in the caller's buffer.
+int mgx_pairhmm_pack_batch(const mgx_pairhmm_input_t* in, uint64_t pair_begin, uint64_t pair_end, void* buf, size_t buf_bytes,
+                           mgx_pairhmm_input_t* out, size_t* need) {
+    int rc = validate(in);
+    if (rc) return rc;
+    if (!out || !need) { set_error("NULL argument"); return -EINVAL; }
+    if (pair_begin > pair_end || pair_end > mgx::pack_n_pairs(in)) { set_error("test-case range outside the stream"); return -EINVAL; }
+    mgx::PackPlan plan;
+    const uint64_t bad = mgx::pack_plan(in, pair_begin, pair_end, &plan);
+    if (bad) { set_error("test case %llu: index out of range", (unsigned long long)(pair_begin + bad - 1)); return -EINVAL; }
+    const uint64_t n = pair_end - pair_begin, nr = plan.lread.size(), nh = plan.lhap.size(), rb = plan.roff.back(), hb = plan.hoff.back();
+    size_t off = 0;
+    const size_t o_roff = off; off = align_up(off + (nr + 1) * 8);
+    const size_t o_hoff = off; off = align_up(off + (nh + 1) * 8);
+    const size_t o_pr = off;   off = align_up(off + n * 4);
+    const size_t o_ph = off;   off = align_up(off + n * 4);
+    const size_t o_b = off;    off = align_up(off + rb);
+    const size_t o_q = off;    off = align_up(off + rb);
+    const size_t o_i = off;    off = align_up(off + rb);
+    const size_t o_d = off;    off = align_up(off + rb);
+    const size_t o_g = off;    off = align_up(off + rb);
+    const size_t o_h = off;    off = align_up(off + hb);
+    *need = off;
+    if (!buf || buf_bytes < off) { set_error("buffer of %zu bytes needed", off); return -ENOSPC; }
+    uint8_t* p = (uint8_t*)buf;
+    memcpy(p + o_roff, plan.roff.data(), (nr + 1) * 8); memcpy(p + o_hoff, plan.hoff.data(), (nh + 1) * 8);
+    memcpy(p + o_pr, plan.pair_read.data(), n * 4);     memcpy(p + o_ph, plan.pair_hap.data(), n * 4);
+    mgx::pack_copy(in, plan, p + o_b, p + o_q, p + o_i, p + o_d, p + o_g, p + o_h);
+    mgx_pairhmm_input_t o{};
+    o.n_reads = nr; o.read_off = (const uint64_t*)(p + o_roff); o.bases = p + o_b; o.qual = p + o_q; o.ins = p + o_i; o.del = p + o_d; o.gcp = p + o_g;
+    o.n_haps = nh; o.hap_off = (const uint64_t*)(p + o_hoff); o.hap_bases = p + o_h;
+    o.n_pairs = n; o.pair_read = (const uint32_t*)(p + o_pr); o.pair_hap = (const uint32_t*)(p + o_ph);
+    *out = o;
     return 0;
 }
 

@@ -27,10 +27,22 @@ class PairHMMStats(C.Structure):
     _fields_ = [
         ("n_pairs", C.c_uint64), ("cells", C.c_uint64), ("alg_bytes", C.c_uint64),
         ("n_rerun_f64", C.c_uint64), ("n_launches_f32", C.c_uint32), ("n_launches_f64", C.c_uint32),
-        ("ms_f32", C.c_float), ("ms_f64", C.c_float), ("ms_f32_dominant", C.c_float),
+        ("n_runs_timed", C.c_uint32), ("ms_f32", C.c_float), ("ms_f64", C.c_float), ("ms_f32_dominant", C.c_float),
         ("dominant_cells", C.c_uint64), ("dominant_alg_bytes", C.c_uint64),
         ("dominant_kernel", C.c_char * 64),
     ]
+
+
+class QueueConfig(C.Structure):
+    _fields_ = [("n_devices", C.c_uint32), ("devices", C.c_void_p), ("lanes_per_device", C.c_uint32),
+                ("depth", C.c_uint32), ("batch_pairs", C.c_uint32), ("flags", C.c_uint)]
+
+
+class QueueStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_batches", C.c_uint64), ("cells", C.c_uint64),
+                ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64), ("seconds", C.c_double),
+                ("pack_seconds", C.c_double), ("wait_seconds", C.c_double), ("n_lanes", C.c_uint32),
+                ("batches_per_device", C.c_uint64 * 16)]
 
 
 class ReadModel(C.Structure):
@@ -54,6 +66,13 @@ PAIRHMM_SYMBOLS = {
     "mgx_read_model_defaults": (None, [C.c_void_p]),
     "mgx_pairhmm_region": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_regions": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_queue_create": (C.c_int, [C.POINTER(QueueConfig), C.POINTER(C.c_void_p)]),
+    "mgx_pairhmm_queue_destroy": (None, [C.c_void_p]),
+    "mgx_pairhmm_queue_run": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_queue_run_range": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_queue_stats": (C.c_int, [C.c_void_p, C.POINTER(QueueStats)]),
+    "mgx_pairhmm_pack_batch": (C.c_int, [C.POINTER(PairHMMInput), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t,
+                                         C.POINTER(PairHMMInput), C.POINTER(C.c_size_t)]),
     "mgx_pairhmm_table_f32": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mgx_pairhmm_table_f64": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
 }

@@ -44,6 +44,76 @@ def make_input(d):
     return inp, keep
 
 
+def pack_batch(d, lo, hi):
+    """The work queue's host packer (no device): test cases [lo, hi) of the stream ``d`` as a
+    self-contained dict in the same packed layout -- every referenced read / haplotype once, in
+    first-use order, local indices."""
+    lib = native.load()
+    inp, keep = make_input(d)
+    out = native.PairHMMInput()
+    need = C.c_size_t()
+    rc = lib.mgx_pairhmm_pack_batch(C.byref(inp), lo, hi, None, 0, C.byref(out), C.byref(need))
+    if rc != -28:          # -ENOSPC is the sizing answer
+        native.check(rc)
+    buf = np.zeros(max(int(need.value), 1), dtype=np.uint8)
+    native.check(lib.mgx_pairhmm_pack_batch(C.byref(inp), lo, hi, _ptr(buf), buf.nbytes, C.byref(out), C.byref(need)))
+    base = buf.ctypes.data
+
+    def view(ptr, count, dt):
+        o = int(ptr or base) - base
+        return buf[o:o + count * np.dtype(dt).itemsize].view(dt).copy()
+    nr, nh, n = int(out.n_reads), int(out.n_haps), int(out.n_pairs)
+    read_off = view(out.read_off, nr + 1, np.uint64); hap_off = view(out.hap_off, nh + 1, np.uint64)
+    rb, hb = int(read_off[-1]), int(hap_off[-1])
+    return dict(n_reads=nr, n_haps=nh, n_pairs=n, read_off=read_off, hap_off=hap_off,
+                bases=view(out.bases, rb, np.uint8), qual=view(out.qual, rb, np.uint8), ins=view(out.ins, rb, np.uint8),
+                dele=view(out.del_, rb, np.uint8), gcp=view(out.gcp, rb, np.uint8), hap_bases=view(out.hap_bases, hb, np.uint8),
+                pair_read=view(out.pair_read, n, np.uint32), pair_hap=view(out.pair_hap, n, np.uint32))
+
+
+class PairHMMQueue:
+    """Host work queue over one or more devices (include/mgx_pairhmm.h, mgx_pairhmm_queue_*):
+    BASELINE.json configs[2], the reference's worker threads pulling regions off an atomic index."""
+
+    def __init__(self, devices=(0,), lanes_per_device=0, depth=0, batch_pairs=0, flags=0):
+        self.lib = native.load()
+        devs = (C.c_int * len(devices))(*devices)
+        cfg = native.QueueConfig(n_devices=len(devices), devices=C.cast(devs, C.c_void_p), lanes_per_device=lanes_per_device,
+                                 depth=depth, batch_pairs=batch_pairs, flags=flags)
+        q = C.c_void_p()
+        native.check(self.lib.mgx_pairhmm_queue_create(C.byref(cfg), C.byref(q)))
+        self.q = q
+
+    def run(self, d, lo=None, hi=None, with_flags=False, prepared=None):
+        """Log10 likelihoods of test cases [lo, hi) of the stream (default: all of it)."""
+        inp, keep = prepared if prepared is not None else make_input(d)
+        total = int(inp.n_pairs)
+        lo = 0 if lo is None else lo
+        hi = total if hi is None else hi
+        out = np.empty(hi - lo, dtype=np.float64)
+        used = np.zeros(hi - lo, dtype=np.uint8) if with_flags else None
+        native.check(self.lib.mgx_pairhmm_queue_run_range(self.q, C.byref(inp), lo, hi, _ptr(out), _ptr(used) if with_flags else None))
+        return (out, used) if with_flags else out
+
+    def stats(self):
+        st = native.QueueStats()
+        native.check(self.lib.mgx_pairhmm_queue_stats(self.q, C.byref(st)))
+        d = {k: getattr(st, k) for k, _ in native.QueueStats._fields_ if k != "batches_per_device"}
+        d["batches_per_device"] = list(st.batches_per_device)
+        return d
+
+    def close(self):
+        if self.q:
+            self.lib.mgx_pairhmm_queue_destroy(self.q)
+            self.q = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PairHMMBatch:
     def __init__(self, engine, d):
         self.engine = engine

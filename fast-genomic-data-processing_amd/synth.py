@@ -109,6 +109,65 @@ def gen_pairhmm_pairs(n_pairs, seed, r_range=(128, 128), h_range=(256, 256),
     return out
 
 
+class _PairHMMParams(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("seed", _C.c_uint64), ("first_pair", _C.c_uint64), ("rmin", _C.c_int), ("rmax", _C.c_int),
+                ("hmin", _C.c_int), ("hmax", _C.c_int), ("sub_thr", _C.c_int), ("n_thr", _C.c_int),
+                ("random_thr", _C.c_double), ("ql", _C.c_int), ("qh", _C.c_int), ("gl", _C.c_int), ("gh", _C.c_int),
+                ("gcp", _C.c_int), ("hap_n_thr", _C.c_int)]
+
+
+_SYNTH_LIB = None
+
+
+def _synth_lib():
+    """libmgx_synth.so: the same streams generated by threaded C++ (csrc/synth/synth_gen.cpp)."""
+    global _SYNTH_LIB
+    if _SYNTH_LIB is None:
+        import ctypes
+        import os
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = os.path.join(here, "libmgx_synth.so")
+        if not os.path.exists(path):
+            from . import build
+            build.build_synth()
+        _SYNTH_LIB = ctypes.CDLL(path)
+    return _SYNTH_LIB
+
+
+def gen_pairhmm_pairs_fast(n_pairs, seed, r_range=(128, 128), h_range=(256, 256), sub_rate=1 / 64, n_rate=1 / 512,
+                           random_read_rate=1 / 128, qual_range=(6, 41), gap_range=(10, 45), gcp=10, hap_n_rate=0.0,
+                           first_pair=0, threads=0, with_pairs=True):
+    """gen_pairhmm_pairs, byte for byte, by the threaded C++ generator: pairs
+    [first_pair, first_pair + n_pairs) of the workload ``seed`` (so a rank can generate only its
+    shard of a long stream).  ``with_pairs=False`` leaves the pair arrays out (pair i = read i x
+    haplotype i is then implied by the caller)."""
+    import ctypes as C
+    import os
+    lib = _synth_lib()
+    threads = threads or min(len(os.sched_getaffinity(0)), 32)
+    prm = _PairHMMParams(seed=seed, first_pair=first_pair, rmin=r_range[0], rmax=r_range[1], hmin=h_range[0], hmax=h_range[1],
+                         sub_thr=int(sub_rate * 65536), n_thr=int((sub_rate + n_rate) * 65536),
+                         random_thr=random_read_rate * 65536.0, ql=qual_range[0], qh=qual_range[1], gl=gap_range[0],
+                         gh=gap_range[1], gcp=gcp, hap_n_thr=int(hap_n_rate * 256) if hap_n_rate > 0 else 0)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    R = np.empty(n_pairs, dtype=np.int64); H = np.empty(n_pairs, dtype=np.int64)
+    lib.synth_pairhmm_lengths(C.byref(prm), C.c_uint64(n_pairs), P(R), P(H), C.c_int(threads))
+    read_off = np.zeros(n_pairs + 1, dtype=np.uint64); hap_off = np.zeros(n_pairs + 1, dtype=np.uint64)
+    np.cumsum(R, out=read_off[1:].view(np.int64)); np.cumsum(H, out=hap_off[1:].view(np.int64))
+    rb, hb = int(read_off[-1]), int(hap_off[-1])
+    arrs = {k: np.empty(rb, dtype=np.uint8) for k in ("bases", "qual", "ins", "dele", "gcp")}
+    hap = np.empty(hb, dtype=np.uint8)
+    lib.synth_pairhmm_fill(C.byref(prm), C.c_uint64(n_pairs), P(read_off), P(hap_off), P(arrs["bases"]), P(arrs["qual"]),
+                           P(arrs["ins"]), P(arrs["dele"]), P(arrs["gcp"]), P(hap), C.c_int(threads))
+    out = dict(n_reads=n_pairs, n_haps=n_pairs, n_pairs=n_pairs, read_off=read_off, hap_off=hap_off, hap_bases=hap, R=R, H=H, **arrs)
+    if with_pairs:
+        out["pair_read"] = np.arange(n_pairs, dtype=np.uint32); out["pair_hap"] = np.arange(n_pairs, dtype=np.uint32)
+    out["cells"] = int((R * H).sum())
+    out["alg_bytes"] = int((5 * R + H + 4).sum())
+    return out
+
+
 def gen_pairhmm_region(n_reads, n_haps, seed, r_range=(20, 128), h_range=(64, 256), dup_reads=0,
                        **kw):
     """An active region: every read against every haplotype (the shape

@@ -35,6 +35,7 @@
 #ifndef MGX_PAIRHMM_H
 #define MGX_PAIRHMM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -79,7 +80,10 @@ typedef struct mgx_pairhmm_stats {
     uint64_t n_rerun_f64;      /* test cases whose fp32 result was < 1e-28f (last run) */
     uint32_t n_launches_f32;   /* kernel launches of the fp32 recurrence per run */
     uint32_t n_launches_f64;
-    /* valid only with MGX_PAIRHMM_TIMING, for the last mgx_pairhmm_batch_run: */
+    /* valid only with MGX_PAIRHMM_TIMING: HIP events recorded on the compute stream around every kernel
+     * of EVERY mgx_pairhmm_batch_run; the figures are means per run over the runs since the previous
+     * mgx_pairhmm_batch_stats call (the last 64 at most), n_runs_timed says how many */
+    uint32_t n_runs_timed;
     float ms_f32;              /* sum of the fp32 recurrence kernels' durations */
     float ms_f64;              /* sum of the fp64 re-run kernels' durations */
     float ms_f32_dominant;     /* duration of the largest fp32 launch ... */
@@ -151,6 +155,48 @@ int mgx_pairhmm_region(mgx_pairhmm_t* ctx, const mgx_pairhmm_input_t* in, const 
 int mgx_pairhmm_regions(mgx_pairhmm_t* ctx, uint32_t n_regions, const mgx_pairhmm_input_t* regions,
                         const uint8_t* const* mapq, const mgx_read_model_t* model,
                         double* const* out_log10, uint8_t* const* out_keep);
+
+
+/* ---- Host work queue (BASELINE.json configs[2]: one long stream of test cases, cut into batches that
+ * worker threads pull off an atomic index -- the reference's threadFunc / atomic region index,
+ * main.cpp:254, and its tail-phase work sharing, main.cpp:302-315, IntelPairHmm.cc:296-330).
+ * A lane is a host thread with its own context (streams, recycled pinned slabs): it packs the next batch
+ * (only the reads / haplotypes its test cases reference cross PCIe, each once), uploads, launches, and
+ * collects a batch's results `depth` batches later, so packing and H2D of batch k+1 overlap the kernels
+ * of batch k.  Lanes of all devices share one counter; there is no collective and no device-to-device
+ * traffic.  Results are identical to mgx_pairhmm_compute on the whole stream. */
+typedef struct mgx_pairhmm_queue mgx_pairhmm_queue_t;
+typedef struct mgx_pairhmm_queue_config {
+    uint32_t n_devices;         /* 0 = one device, ordinal 0 */
+    const int* devices;         /* [n_devices] HIP ordinals (an ordinal may repeat) */
+    uint32_t lanes_per_device;  /* host threads per device; 0 = 4 */
+    uint32_t depth;             /* batches in flight per lane; 0 = 2 */
+    uint32_t batch_pairs;       /* test cases per batch; 0 = 65536 */
+    unsigned flags;             /* as mgx_pairhmm_create */
+} mgx_pairhmm_queue_config_t;
+typedef struct mgx_pairhmm_queue_stats {
+    uint64_t n_pairs, n_batches, cells;
+    uint64_t bytes_h2d, bytes_d2h;      /* what crossed PCIe */
+    double seconds;                     /* wall time of the last run, host buffers in -> results in host memory */
+    double pack_seconds, wait_seconds;  /* summed over lanes: planning + packing | blocked on the device */
+    uint32_t n_lanes;
+    uint64_t batches_per_device[16];
+} mgx_pairhmm_queue_stats_t;
+int mgx_pairhmm_queue_create(const mgx_pairhmm_queue_config_t* cfg, mgx_pairhmm_queue_t** out);
+void mgx_pairhmm_queue_destroy(mgx_pairhmm_queue_t* q);
+/* Synchronous: the whole stream `in` (pair list, or cross-product form enumerated read-major) in,
+ * out_log10[i] for test case i out; used_f64 may be NULL. */
+int mgx_pairhmm_queue_run(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_t* in, double* out_log10, uint8_t* used_f64);
+/* The same for test cases [pair_begin, pair_end) only -- the shard of one process when the stream is
+ * split over several (one process per GPU): out_log10[i - pair_begin]. */
+int mgx_pairhmm_queue_run_range(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_t* in, uint64_t pair_begin, uint64_t pair_end,
+                                double* out_log10, uint8_t* used_f64);
+int mgx_pairhmm_queue_stats(mgx_pairhmm_queue_t* q, mgx_pairhmm_queue_stats_t* out);
+/* Host only (no device): the queue's packer.  Test cases [pair_begin, pair_end) of `in` as a self-contained
+ * batch laid out in buf: *out points into buf, local indices, every referenced read / haplotype once, in
+ * first-use order.  *need receives the bytes required; -ENOSPC if buf_bytes is smaller (buf may be NULL). */
+int mgx_pairhmm_pack_batch(const mgx_pairhmm_input_t* in, uint64_t pair_begin, uint64_t pair_end, void* buf, size_t buf_bytes,
+                           mgx_pairhmm_input_t* out, size_t* need);
 
 /* The two probability tables as built by the product (for table-parity tests):
  * which = 0: ph2pr[128]; which = 1: matchToMatchProb[32640].  Returns the element count. */
