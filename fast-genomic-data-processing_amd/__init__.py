@@ -7,6 +7,6 @@ been built, or no HIP device is visible, every entry point raises.
 from . import native  # noqa: F401
 from .native import MgxError, lib_path, load  # noqa: F401
 from .pairhmm import PairHMMEngine, PairHMMBatch, PairHMMQueue  # noqa: F401
-from .sortdedup import SortDedupEngine  # noqa: F401
+from .sortdedup import SortDedupEngine, Routed  # noqa: F401
 from .smithwaterman import SmithWatermanEngine  # noqa: F401
 from . import pairhmm, sortdedup, smithwaterman, synth  # noqa: F401

@@ -181,9 +181,11 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
         int c = 0;
         u64 wa = 0, wb = 0;
         if (i < n) {
-            o.ckey[i] = o.packed_coord ? (coord[k] << 32) | i : coord[k];
-            if (!o.packed_coord) o.cval[i] = i;
-            m_coord = max(m_coord, coord[k]);
+            if (o.ckey) {      // (a shard's ordering half is a different record subset: k_order_keys writes the keys then)
+                o.ckey[i] = o.packed_coord ? (coord[k] << 32) | i : coord[k];
+                if (!o.packed_coord) o.cval[i] = i;
+                m_coord = max(m_coord, coord[k]);
+            }
             if (!(flag[k] & kIgnorable)) c = mate[k] == MGX_NO_MATE ? 2 : (mate[k] > i ? 1 : 0);
             if (c == 1) {
                 // DoublePair::DoublePair, pair.cpp:71-108
@@ -261,6 +263,43 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
                  : threadIdx.x == 3 ? &sc->max_k1s : &sc->max_near;
         if (v > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, v);
     }
+}
+
+// Sharded input (mgx_sortdedup_upload_shard): the records a shard ORDERS are not the records it MARKS, so the
+// coordinate keys come from the routed (coordinate, global arrival index) arrays instead of the build kernel.
+__global__ __launch_bounds__(256) void k_order_keys(const u64* __restrict__ coord, const u32* __restrict__ arrival, u32 n,
+                                                    u64* __restrict__ ckey, u32* __restrict__ cval, int packed, Scalars* sc) {
+    __shared__ u64 smax[4];
+    u64 m = 0;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const u64 cd = coord[i];
+        const u32 a = arrival[i];
+        ckey[i] = packed ? (cd << 32) | a : cd;
+        if (!packed) cval[i] = a;
+        m = max(m, cd);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (u64)__shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 v = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+        if (v > __atomic_load_n(&sc->max_coord, __ATOMIC_RELAXED)) atomicMax(&sc->max_coord, v);
+    }
+}
+
+// Indicator marks routed from other shards (5' position << 1 | reverse half): ORed into the bitmap after the
+// shard's own pairs have defined it and before its fragments are tested.  In the tiled layout a position at or
+// beyond L - 64 cannot be hit by any of this shard's fragments (the layout is only chosen when all of its own
+// 5' ends are below), so such a mark is dropped instead of aliasing into the other half.
+__global__ __launch_bounds__(256) void k_or_marks(const u64* __restrict__ marks, u32 n, u32* __restrict__ indicator, u64 ind_bits,
+                                                  u64 ind_off, u64 fwd_limit) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 mk = marks[i], pos = mk >> 1;
+    if (pos >= fwd_limit) return;
+    const u64 b = pos + ((mk & 1) ? ind_off : 0ull);
+    if (b < ind_bits) atomicOr(&indicator[b >> 5], 1u << (b & 31));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -971,7 +1010,11 @@ struct mgx_sortdedup {
     hipStream_t compute = nullptr, copy = nullptr;
     int n_cu = 256;
     uint64_t L = 0;
-    u32 n = 0;
+    u32 n = 0;                             // records the duplicate search works on (the marking half of a shard)
+    u32 n_order = 0;                       // records the coordinate sort orders (== n unless the input is a shard)
+    bool sharded = false;
+    u64* d_ocoord = nullptr; u32* d_oarr = nullptr; size_t order_cap = 0;   // a shard's ordering half as uploaded
+    u64* d_marks = nullptr; size_t marks_cap = 0; u32 n_marks = 0;          // indicator marks routed from other shards
     size_t cap = 0;                        // record capacity of the buffers below
     mgx_rec_t* d_recs = nullptr;
     u64 *d_ckey[2] = {nullptr, nullptr}; u32* d_cval[2] = {nullptr, nullptr};
@@ -1182,6 +1225,7 @@ void mgx_sortdedup_destroy(mgx_sortdedup_t* c) {
     (void)hipSetDevice(c->device);
     free_buffers(c);
     (void)hipFree(c->d_indicator); (void)hipFree(c->d_sub_start); (void)hipFree(c->d_sc);
+    (void)hipFree(c->d_ocoord); (void)hipFree(c->d_oarr); (void)hipFree(c->d_marks);
     for (int i = 0; i < 2; ++i) { if (c->pinned[i]) (void)hipHostFree(c->pinned[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
     for (auto e : c->ev_scatter) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1193,13 +1237,12 @@ void mgx_sortdedup_destroy(mgx_sortdedup_t* c) {
     delete c;
 }
 
-int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, const mgx_rec_t* recs) {
-    if (!c) { set_error("ctx is NULL"); return -EINVAL; }
-    if (n_records >= 0xFFFFFFF0ull) { set_error("more than 2^32 records in one shard"); return -E2BIG; }
-    if (n_records && !recs) { set_error("recs is NULL"); return -EINVAL; }
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_capacity(c, (size_t)n_records);
-    if (rc) { set_error("out of device memory for %llu records", (unsigned long long)n_records); return rc; }
+namespace {
+
+// bitmap, sub-tile table and the per-input decisions shared by both upload forms
+int prepare_input(mgx_sortdedup_t* c, uint64_t L, size_t capacity) {
+    int rc = ensure_capacity(c, capacity);
+    if (rc) { set_error("out of device memory for %zu records", capacity); return rc; }
     // double_pair_indicator: 4L bits like the reference (main.cpp:115)
     const uint64_t Lp = (L + kIndTile - 1) / kIndTile * kIndTile;          // tile-aligned reverse offset
     const uint64_t bits = std::max<uint64_t>(4 * L + 64, 2 * Lp + 2 * (uint64_t)kIndTile);
@@ -1218,14 +1261,19 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
         }
     }
     c->indicator_bits = 4 * L;
-    c->L = L; c->n = (u32)n_records; c->ran = false;
+    c->L = L; c->ran = false;
     c->near_by_position = true;             // decided again for every input (see finish_run)
     c->packed_coord = L < 0xFFFFFFFFull;     // coord <= L (bam_record.cpp:18-24)
     c->packed_pair = L < 0xF0000000ull;      // 5' ends <= L + clip; verified against the device maximum
-    // records are streamed through two pinned staging buffers on the copy stream
-    const size_t total = (size_t)n_records * sizeof(mgx_rec_t);
+    return 0;
+}
+
+// host memory -> HBM through two pinned staging buffers on the copy stream (asynchronous; the caller syncs)
+int stream_up(mgx_sortdedup_t* c, void* dst, const void* src_, size_t total) {
+    if (!total) return 0;
     const size_t chunk = std::min(kPinnedChunk, std::max<size_t>((total + 1) / 2, 1u << 20));
     if (chunk > c->pinned_cap) {
+        HIP_TRY(hipStreamSynchronize(c->copy));
         for (int i = 0; i < 2; ++i) { if (c->pinned[i]) (void)hipHostFree(c->pinned[i]); c->pinned[i] = nullptr; }
         c->pinned_cap = 0;
         for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&c->pinned[i], chunk, hipHostMallocDefault));
@@ -1240,21 +1288,63 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, con
             // one core copies ~12 GB/s into the staging buffer, less than half of what the link takes:
             // split the chunk over a few threads (MGX_UPLOAD_THREADS, default 4)
             static const int n_thr = [] { const char* e = getenv("MGX_UPLOAD_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-            const char* src = reinterpret_cast<const char*>(recs) + off;
-            char* dst = static_cast<char*>(c->pinned[buf]);
-            if (n_thr == 1 || len < (8u << 20)) memcpy(dst, src, len);
+            const char* src = reinterpret_cast<const char*>(src_) + off;
+            char* stage = static_cast<char*>(c->pinned[buf]);
+            if (n_thr == 1 || len < (8u << 20)) memcpy(stage, src, len);
             else {
                 std::thread th[16];
                 const size_t part = (len / (size_t)n_thr + 4095) & ~(size_t)4095;
                 int used = 0;
-                for (size_t o = 0; o < len; o += part) th[used++] = std::thread([=] { memcpy(dst + o, src + o, std::min(part, len - o)); });
+                for (size_t o = 0; o < len; o += part) th[used++] = std::thread([=] { memcpy(stage + o, src + o, std::min(part, len - o)); });
                 for (int t = 0; t < used; ++t) th[t].join();
             }
         }
-        HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c->d_recs) + off, c->pinned[buf], len, hipMemcpyHostToDevice, c->copy));
+        HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, c->pinned[buf], len, hipMemcpyHostToDevice, c->copy));
         HIP_TRY(hipEventRecord(c->pin_ev[buf], c->copy));
         off += len; buf ^= 1;
     }
+    return 0;
+}
+
+}  // namespace
+
+int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, const mgx_rec_t* recs) {
+    if (!c) { set_error("ctx is NULL"); return -EINVAL; }
+    if (n_records >= 0xFFFFFFF0ull) { set_error("more than 2^32 records in one shard"); return -E2BIG; }
+    if (n_records && !recs) { set_error("recs is NULL"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = prepare_input(c, L, (size_t)n_records);
+    if (rc) return rc;
+    c->n = c->n_order = (u32)n_records; c->sharded = false; c->n_marks = 0;
+    // records are streamed through two pinned staging buffers on the copy stream
+    if ((rc = stream_up(c, c->d_recs, recs, (size_t)n_records * sizeof(mgx_rec_t)))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    return 0;
+}
+
+int mgx_sortdedup_upload_shard(mgx_sortdedup_t* c, uint64_t L, const mgx_sortdedup_shard_t* sh) {
+    if (!c || !sh) { set_error("NULL argument"); return -EINVAL; }
+    if (sh->n_order >= 0xFFFFFFF0ull || sh->n_mark >= 0xFFFFFFF0ull || sh->n_marks >= 0xFFFFFFF0ull) { set_error("more than 2^32 entries in one shard"); return -E2BIG; }
+    if ((sh->n_order && (!sh->order_coord || !sh->order_arrival)) || (sh->n_mark && (!sh->mark_recs || !sh->mark_arrival)) ||
+        (sh->n_marks && !sh->marks)) { set_error("a shard array is NULL (was the shard materialised by mgx_sortdedup_route?)"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = prepare_input(c, L, (size_t)std::max(sh->n_order, sh->n_mark));
+    if (rc) return rc;
+    if (sh->n_order > c->order_cap) {
+        (void)hipFree(c->d_ocoord); (void)hipFree(c->d_oarr); c->d_ocoord = nullptr; c->d_oarr = nullptr; c->order_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_ocoord, sh->n_order * 8)); HIP_TRY(hipMalloc((void**)&c->d_oarr, sh->n_order * 4));
+        c->order_cap = sh->n_order;
+    }
+    if (sh->n_marks > c->marks_cap) {
+        (void)hipFree(c->d_marks); c->d_marks = nullptr; c->marks_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_marks, sh->n_marks * 8));
+        c->marks_cap = sh->n_marks;
+    }
+    c->n = (u32)sh->n_mark; c->n_order = (u32)sh->n_order; c->n_marks = (u32)sh->n_marks; c->sharded = true;
+    if ((rc = stream_up(c, c->d_recs, sh->mark_recs, (size_t)sh->n_mark * sizeof(mgx_rec_t)))) return rc;
+    if ((rc = stream_up(c, c->d_ocoord, sh->order_coord, (size_t)sh->n_order * 8))) return rc;
+    if ((rc = stream_up(c, c->d_oarr, sh->order_arrival, (size_t)sh->n_order * 4))) return rc;
+    if ((rc = stream_up(c, c->d_marks, sh->marks, (size_t)sh->n_marks * 8))) return rc;
     HIP_TRY(hipStreamSynchronize(c->copy));
     return 0;
 }
@@ -1263,9 +1353,9 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     if (!c) { set_error("ctx is NULL"); return -EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->compute;
-    const u32 n = c->n;
+    const u32 n = c->n, n_order = c->n_order;
     c->stats = mgx_sortdedup_stats_t{};
-    c->stats.n_records = n;
+    c->stats.n_records = n_order;
     c->ev_used = 0; c->scatter_bytes = 0;
     HIP_TRY(hipEventRecord(c->ev_start, s));
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1273,12 +1363,15 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         if (n) {
             HIP_TRY(hipMemsetAsync(c->d_dup, 0, n, s));
             const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
-            BuildOut o{c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
+            BuildOut o{c->sharded ? nullptr : c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
                        c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0, c->packed_pair ? 1 : 0,
                        c->d_nk[0], c->d_nrec[0], c->packed_pair ? 1 : 0, n < 0x80000000u ? 0x80000000u : 0u};
             hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, o, c->d_sc);
             HIP_TRY(hipGetLastError());
         }
+        if (c->sharded && n_order)
+            hipLaunchKernelGGL(k_order_keys, dim3(std::min<u32>((n_order + 255) / 256, (u32)c->n_cu * 16)), dim3(256), 0, s, c->d_ocoord, c->d_oarr,
+                               n_order, c->d_ckey[0], c->d_cval[0], c->packed_coord ? 1 : 0, c->d_sc);
         // the only host round trip: entry counts and key maxima size the sorts
         HIP_TRY(hipMemcpyAsync(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -1358,11 +1451,11 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     const uint64_t bytes_before_records = c->scatter_bytes;
     if (c->packed_coord) {
         // key = coord << 32 | arrival index: sort on the high half only, 8 bytes per record per pass
-        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n, 32, bits_of(c->sc.max_coord), &ccur, c->d_cval[0], &unpacked))) return rc;
-        if (n && !unpacked) hipLaunchKernelGGL(k_unpack_order, dim3((n + 255) / 256), dim3(256), 0, sR, c->d_ckey[ccur], n, c->d_cval[0]);
+        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n_order, 32, bits_of(c->sc.max_coord), &ccur, c->d_cval[0], &unpacked))) return rc;
+        if (n_order && !unpacked) hipLaunchKernelGGL(k_unpack_order, dim3((n_order + 255) / 256), dim3(256), 0, sR, c->d_ckey[ccur], n_order, c->d_cval[0]);
         ccur = 0;
     } else {
-        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, c->d_cval, n, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
+        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, c->d_cval, n_order, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
     }
     c->order_buf = ccur;
     c->ev_rec_end = c->ev_used;
@@ -1371,7 +1464,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         // the statistics of "the record-sort scatter kernel" cover the full-width launches only; the
         // last one is a different instantiation (half the store bytes)
         c->ev_rec_end -= 2;
-        c->rec_scatter_bytes -= (uint64_t)n * 12;
+        c->rec_scatter_bytes -= (uint64_t)n_order * 12;
     }
     HIP_TRY(hipEventRecord(c->ev_side[1], sR));
 
@@ -1401,6 +1494,9 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
         if (pk) hipLaunchKernelGGL((k_set_indicator<2, true>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
         else    hipLaunchKernelGGL((k_set_indicator<2, false>), dim3((nd + 255) / 256), dim3(256), 0, s, c->d_k1[cur], c->d_k2[cur], nd, c->d_indicator, c->indicator_bits, c->L);
     }
+    if (n && c->n_marks)      // ends of pairs that live in other shards
+        hipLaunchKernelGGL(k_or_marks, dim3((c->n_marks + 255) / 256), dim3(256), 0, s, c->d_marks, c->n_marks, c->d_indicator, ind_bits, ind_off,
+                           tiled ? c->L - 64 : ~0ull);
     if ((rc = radix_sort(c, s, c->scr[0], c->d_k1, c->d_k2, pk ? nullptr : c->d_prec, nd, 0, bits_of(c->sc.max_k1d), &cur))) return rc;
     if (nd) {
         const dim3 g((nd + 255) / 256);
@@ -1452,9 +1548,9 @@ int mgx_sortdedup_results(mgx_sortdedup_t* c, uint32_t* out_order, uint8_t* out_
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = finish_run(c); if (rc) return rc; }
     if (c->n) {
-        if (out_order) HIP_TRY(hipMemcpyAsync(out_order, c->d_cval[c->order_buf], (size_t)c->n * 4, hipMemcpyDeviceToHost, c->compute));
         if (out_dup) HIP_TRY(hipMemcpyAsync(out_dup, c->d_dup, (size_t)c->n, hipMemcpyDeviceToHost, c->compute));
     }
+    if (c->n_order && out_order) HIP_TRY(hipMemcpyAsync(out_order, c->d_cval[c->order_buf], (size_t)c->n_order * 4, hipMemcpyDeviceToHost, c->compute));
     HIP_TRY(hipStreamSynchronize(c->compute));
     return 0;
 }
@@ -1481,7 +1577,7 @@ int mgx_sortdedup_stats(mgx_sortdedup_t* c, mgx_sortdedup_stats_t* out) {
         st.ms_scatter_records += ms; st.n_scatter_records++;
     }
     // LSD-8 traffic model, SURVEY.md section 8d
-    const uint64_t N = c->n, P = (uint64_t)st.n_double + st.n_single;
+    const uint64_t N = c->n_order, P = (uint64_t)st.n_double + st.n_single;
     const uint64_t pc = (st.key_bits_coord + 7) / 8, pp = (st.key_bits_pair1 + st.key_bits_pair2 + 7) / 8;
     st.alg_bytes = N * (8 + pc * 2 * 12) + P * (16 + pp * 2 * 20) + P * 29 + N;
     *out = st;

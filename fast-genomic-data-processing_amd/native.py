@@ -129,7 +129,19 @@ class SortDedupStats(C.Structure):
     ]
 
 
+class SortDedupShard(C.Structure):
+    _fields_ = [("n_order", C.c_uint64), ("order_coord", C.c_void_p), ("order_arrival", C.c_void_p),
+                ("n_mark", C.c_uint64), ("mark_recs", C.c_void_p), ("mark_arrival", C.c_void_p),
+                ("n_marks", C.c_uint64), ("marks", C.c_void_p), ("order_base", C.c_uint64),
+                ("coord_lo", C.c_uint64), ("coord_hi", C.c_uint64)]
+
+
 SORTDEDUP_SYMBOLS = {
+    "mgx_sortdedup_route": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "mgx_sortdedup_routed_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(SortDedupShard)]),
+    "mgx_sortdedup_routed_free": (None, [C.c_void_p]),
+    "mgx_sortdedup_upload_shard": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(SortDedupShard)]),
+    "mgx_sortdedup_merge": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_sortdedup_pack": (C.c_int, [C.POINTER(RawRecords), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "mgx_sortdedup_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
     "mgx_sortdedup_destroy": (None, [C.c_void_p]),

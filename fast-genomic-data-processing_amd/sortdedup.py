@@ -35,6 +35,52 @@ def pack(raw):
     return recs, idx, int(L.value)
 
 
+class Routed:
+    """One record set cut into coordinate shards by the host router (mgx_sortdedup_route): the
+    reference's range partitioners + shared bitmap, for GPUs that share nothing."""
+
+    def __init__(self, L, recs, n_shards, only_shard=-1):
+        self.lib = native.load()
+        recs = np.ascontiguousarray(recs)
+        assert recs.dtype == REC_DTYPE
+        self.L, self.n_records, self.n_shards = int(L), len(recs), n_shards
+        h = C.c_void_p()
+        native.check(self.lib.mgx_sortdedup_route(self.L, self.n_records, _ptr(recs), n_shards, only_shard, C.byref(h)))
+        self.h = h
+
+    def shard(self, k):
+        sh = native.SortDedupShard()
+        native.check(self.lib.mgx_sortdedup_routed_shard(self.h, k, C.byref(sh)))
+        return sh
+
+    def shard_arrays(self, k):
+        """Copies of shard k's arrays (tests / the CPU checker)."""
+        sh = self.shard(k)
+
+        def view(ptr, count, dt):
+            if not count:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dt).itemsize,)).view(dt).copy()
+        return dict(order_coord=view(sh.order_coord, sh.n_order, np.uint64), order_arrival=view(sh.order_arrival, sh.n_order, np.uint32),
+                    mark_recs=view(sh.mark_recs, sh.n_mark, REC_DTYPE), mark_arrival=view(sh.mark_arrival, sh.n_mark, np.uint32),
+                    marks=view(sh.marks, sh.n_marks, np.uint64), order_base=int(sh.order_base), coord_lo=int(sh.coord_lo), coord_hi=int(sh.coord_hi))
+
+    def merge(self, k, shard_order, shard_dup, out_order, out_dup):
+        native.check(self.lib.mgx_sortdedup_merge(self.h, k, _ptr(np.ascontiguousarray(shard_order)), _ptr(np.ascontiguousarray(shard_dup)),
+                                                  _ptr(out_order), _ptr(out_dup)))
+
+    def close(self):
+        if self.h:
+            self.lib.mgx_sortdedup_routed_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SortDedupEngine:
     def __init__(self, device=0, flags=0):
         self.lib = native.load()
@@ -46,14 +92,21 @@ class SortDedupEngine:
     def upload(self, L, recs):
         recs = np.ascontiguousarray(recs)
         assert recs.dtype == REC_DTYPE
-        self.n = len(recs)
+        self.n = self.n_order = len(recs)
         native.check(self.lib.mgx_sortdedup_upload(self.ctx, L, self.n, _ptr(recs)))
+
+    def upload_shard(self, routed, k):
+        """One shard of a routed record set: results() then returns (global arrival indices of the shard's
+        records in output order, duplicate flag per marking record)."""
+        sh = routed.shard(k)
+        self.n, self.n_order = int(sh.n_mark), int(sh.n_order)
+        native.check(self.lib.mgx_sortdedup_upload_shard(self.ctx, routed.L, C.byref(sh)))
 
     def run(self):
         native.check(self.lib.mgx_sortdedup_run(self.ctx))
 
     def results(self):
-        order = np.empty(self.n, dtype=np.uint32)
+        order = np.empty(getattr(self, "n_order", self.n), dtype=np.uint32)
         dup = np.empty(self.n, dtype=np.uint8)
         native.check(self.lib.mgx_sortdedup_results(self.ctx, _ptr(order), _ptr(dup)))
         return order, dup

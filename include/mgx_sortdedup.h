@@ -105,6 +105,48 @@ int mgx_sortdedup_stats(mgx_sortdedup_t* ctx, mgx_sortdedup_stats_t* out);
 int mgx_sortdedup_sort_mark(mgx_sortdedup_t* ctx, uint64_t L, uint64_t n_records,
                             const mgx_rec_t* recs, uint32_t* out_order, uint8_t* out_dup);
 
+
+/* ---- One record set over several GPUs (reference: the three range partitioners and the global
+ * double_pair_indicator, sortmardup/tbb/range_partitioner.h:98-100, tbb/bam_partitioner.cpp:31-33,
+ * main.cpp:160-192).  The host router cuts the arrival-ordered records into n_shards coordinate ranges of equal
+ * width; each shard is TWO subsets of the input plus the marks that cross shard boundaries:
+ *   ordering half  the records whose unified coordinate lies in the range (bam_partitioner)
+ *   marking half   the templates keyed in the range -- pairs by their smaller 5' end, fragments by their 5' end
+ *                  (double_partitioner / single_partitioner) -- as records with shard-local mate indices
+ *   marks          5' ends of pairs that live in other shards but fall into this range: what the reference
+ *                  writes into the shared bitmap becomes the only data exchanged between shards
+ * A shard runs on any context with mgx_sortdedup_upload_shard + run + results; no collective is involved.
+ * Concatenating the shards' orders in shard order is the global order; mgx_sortdedup_merge does that and
+ * scatters the duplicate flags back to arrival indices.  Results are bit-identical to the single-shard call. */
+typedef struct mgx_sortdedup_shard {
+    uint64_t n_order;
+    const uint64_t* order_coord;     /* [n_order] unified coordinate, arrival order kept */
+    const uint32_t* order_arrival;   /* [n_order] global arrival index */
+    uint64_t n_mark;
+    const mgx_rec_t* mark_recs;      /* [n_mark] records 1 and 2 of a template adjacent, mate = shard-local index */
+    const uint32_t* mark_arrival;    /* [n_mark] global arrival index of each marking record */
+    uint64_t n_marks;
+    const uint64_t* marks;           /* [n_marks] 5' position << 1 | 1 if it belongs to the reverse-strand half */
+    uint64_t order_base;             /* where this shard's order starts in the global output */
+    uint64_t coord_lo, coord_hi;     /* the shard's range [lo, hi) of coordinates / 5' positions */
+} mgx_sortdedup_shard_t;
+typedef struct mgx_sortdedup_routed mgx_sortdedup_routed_t;
+
+/* Host side.  only_shard < 0 materialises every shard; otherwise only that one (a process that owns one GPU
+ * routes the whole input but keeps its own shard; sizes and order_base of the others are still filled in). */
+int mgx_sortdedup_route(uint64_t L, uint64_t n_records, const mgx_rec_t* recs, uint32_t n_shards, int only_shard,
+                        mgx_sortdedup_routed_t** out);
+int mgx_sortdedup_routed_shard(const mgx_sortdedup_routed_t* routed, uint32_t k, mgx_sortdedup_shard_t* out);
+void mgx_sortdedup_routed_free(mgx_sortdedup_routed_t* routed);
+/* Device side: upload one shard.  After mgx_sortdedup_run, mgx_sortdedup_results returns
+ *   out_order[n_order]  global arrival indices of the shard's records in output order
+ *   out_dup[n_mark]     duplicate flag of every marking record (index into mark_recs / mark_arrival) */
+int mgx_sortdedup_upload_shard(mgx_sortdedup_t* ctx, uint64_t L, const mgx_sortdedup_shard_t* shard);
+/* Host side: shard k's results into the global arrays (out_order[n_records], out_dup[n_records], zero-initialised
+ * by the caller; either may be NULL). */
+int mgx_sortdedup_merge(const mgx_sortdedup_routed_t* routed, uint32_t k, const uint32_t* shard_order, const uint8_t* shard_dup,
+                        uint32_t* out_order, uint8_t* out_dup);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,8 +177,13 @@ static int bit_get(const uint64_t* bm, uint64_t p) { return p < g_bits ? (int)((
 
 /* out_order[k] = arrival index of the k-th output record; out_dup[i] = 1 iff record i is marked.
  * counts (may be NULL): [0] doubles, [1] singles, [2] duplicate records. */
-int sd_oracle_run(uint64_t L, uint64_t n, const rec_t* recs, uint32_t* out_order, uint8_t* out_dup,
-                  uint64_t* counts) {
+/* Shard form (one record set over several GPUs): the records that are MARKED (recs, shard-local
+ * mate indices) are not the records that are ORDERED (order_coord / order_arrival, n_order entries; NULL = order
+ * recs themselves), and `marks` (position << 1 | reverse half) are the ends of pairs living in other shards --
+ * what the reference's workers write into the one shared bitmap (main.cpp:181-192). */
+int sd_oracle_run_shard(uint64_t L, uint64_t n, const rec_t* recs, uint64_t n_order, const uint64_t* order_coord,
+                        const uint32_t* order_arrival, uint64_t n_marks, const uint64_t* marks, uint32_t* out_order,
+                        uint8_t* out_dup, uint64_t* counts) {
     pair_t* dbl = (pair_t*)malloc(sizeof(pair_t) * (n / 2 + 1));
     pair_t* sgl = (pair_t*)malloc(sizeof(pair_t) * (n + 1));
     uint64_t nd = 0, ns = 0;
@@ -188,6 +193,7 @@ int sd_oracle_run(uint64_t L, uint64_t n, const rec_t* recs, uint32_t* out_order
     uint64_t* indicator = (uint64_t*)calloc((maxbit >> 6) + 2, 8);
     g_bits = maxbit;
     memset(out_dup, 0, n);
+    for (uint64_t i = 0; i < n_marks; i++) bit_set(indicator, (marks[i] >> 1) + ((marks[i] & 1) ? L : 0));
     for (uint64_t i = 0; i < n; i++) {
         const rec_t* r1 = &recs[i];
         int ign = (r1->flag & (0x4 | 0x100 | 0x800)) != 0;
@@ -233,12 +239,22 @@ int sd_oracle_run(uint64_t L, uint64_t n, const rec_t* recs, uint32_t* out_order
         for (j = i + 1; j < ns && sgl[j].key1 == sgl[i].key1; j++) out_dup[sgl[j].rec] = 1;
         i = j;
     }
-    ckey_t* ck = (ckey_t*)malloc(sizeof(ckey_t) * (n + 1));
-    for (uint64_t i = 0; i < n; i++) { ck[i].coord = recs[i].coord; ck[i].idx = (uint32_t)i; }
-    qsort(ck, n, sizeof(ckey_t), cmp_coord);                               /* main.cpp:348-357 */
+    const uint64_t no = order_coord ? n_order : n;
+    ckey_t* ck = (ckey_t*)malloc(sizeof(ckey_t) * (no + 1));
+    for (uint64_t i = 0; i < no; i++) {
+        ck[i].coord = order_coord ? order_coord[i] : recs[i].coord;
+        ck[i].idx = order_coord ? order_arrival[i] : (uint32_t)i;
+    }
+    qsort(ck, no, sizeof(ckey_t), cmp_coord);                              /* main.cpp:348-357 */
     uint64_t ndup = 0;
-    for (uint64_t i = 0; i < n; i++) { out_order[i] = ck[i].idx; ndup += out_dup[i]; }
+    for (uint64_t i = 0; i < no; i++) out_order[i] = ck[i].idx;
+    for (uint64_t i = 0; i < n; i++) ndup += out_dup[i];
     if (counts) { counts[0] = nd; counts[1] = ns; counts[2] = ndup; }
     free(ck); free(indicator); free(dbl); free(sgl);
     return 0;
+}
+
+int sd_oracle_run(uint64_t L, uint64_t n, const rec_t* recs, uint32_t* out_order, uint8_t* out_dup,
+                  uint64_t* counts) {
+    return sd_oracle_run_shard(L, n, recs, 0, NULL, NULL, 0, NULL, out_order, out_dup, counts);
 }
