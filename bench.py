@@ -86,12 +86,24 @@ def cpu_baseline(synth, n_sample, seed):
 
 
 def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend="nccl"):
-    """GPU radix sort + duplicate marking over a resident shard of packed records; every rank owns a
-    coordinate-independent shard of its own (weak scaling, no collective on the data path)."""
-    recs, L = synth.gen_sortdedup_packed(args.sort_records, 0x5EED0004 + 0x1000 * rank)
+    """GPU radix sorts + duplicate marking of BASELINE.json configs[3], records resident in HBM.  N = 1: the whole
+    200 M-record set on one GPU.  N > 1: the SAME set (every rank generates it from the same seed) routed into N
+    coordinate shards by the host router -- records by coordinate, templates by their smaller 5' end, bitmap marks
+    to the shard that owns the position -- and rank r runs shard r; no collective on the data path."""
+    recs, L = synth.gen_sortdedup_packed_fast(args.sort_records, 0x5EED0004)
     eng = pkg.SortDedupEngine(local_rank)
+    route_s, shard_info = 0.0, None
     t0 = time.perf_counter()
-    eng.upload(L, recs)
+    if world == 1:
+        eng.upload(L, recs)
+    else:
+        routed = pkg.Routed(L, recs, world, only_shard=rank)
+        route_s = time.perf_counter() - t0
+        sh = routed.shard(rank)
+        shard_info = {"n_order": int(sh.n_order), "n_mark": int(sh.n_mark), "n_marks_routed_in": int(sh.n_marks),
+                      "coord_lo": int(sh.coord_lo), "coord_hi": min(int(sh.coord_hi), L + 1)}
+        t0 = time.perf_counter()
+        eng.upload_shard(routed, rank)
     upload_s = time.perf_counter() - t0
     for _ in range(2):
         eng.run()
@@ -112,6 +124,13 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backe
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
+    if world > 1:
+        # outside the timed region: this rank's slice of the global order is sorted and lies in its coordinate range
+        order, dup = eng.results()
+        cs = recs["coord"][order]
+        assert (np.diff(cs.astype(np.int64)) >= 0).all() and (len(cs) == 0 or (cs[0] >= shard_info["coord_lo"] and cs[-1] < max(shard_info["coord_hi"], L + 1)))
+        shard_info["dup_marked"] = int(dup.sum())
+        routed.close()
     out = None
     if rank == 0:
         n = len(recs)
@@ -127,18 +146,21 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backe
         ms_scatter_avg = st1["ms_scatter_records"] / n_dom
         bytes_per_scatter = st1["scatter_records_bytes"] / n_dom
         achieved = st1["scatter_records_bytes"] / max(st1["ms_scatter_records"], 1e-9) / 1e6
-        out = {"metric": "sortmardup Mrecords/s", "value": n * world * args.sort_steps / tmax / 1e6,
+        out = {"metric": "sortmardup Mrecords/s", "value": n * args.sort_steps / tmax / 1e6,
                "unit": "Mrecords/s", "n_gpus": world, "steps": args.sort_steps, "ms_per_step": tmax / args.sort_steps * 1e3,
-               "dtype": "u64", "scaling": "weak",
-               "config": {"workload": "BASELINE.json configs[3]: synthetic packed BAM records per GPU, 97% in proper "
-                                      "pairs, 10% duplicate pairs, L=3.1e9; radix sorts + duplicate search, records resident in HBM",
-                          "records_per_gpu": n, "n_double": st["n_double"], "n_single": st["n_single"],
-                          "dup_records": st["n_dup_records"], "radix_passes": st["n_radix_passes"]},
-               "device_ms": st["ms_total"], "upload_s": upload_s,
-               "pcie_inclusive_mrecords_s": n / (upload_s + st["ms_total"] * 1e-3) / 1e6,
+               "dtype": "u64", "scaling": "strong",
+               "config": {"workload": f"BASELINE.json configs[3]: ONE set of {n} synthetic packed BAM records, 97% in proper "
+                                      "pairs, 10% duplicate pairs, L=3.1e9; radix sorts + duplicate search, records resident in HBM"
+                                      + ("" if world == 1 else f"; routed into {world} coordinate shards by the host router, one per GPU "
+                                                                "(rank 0's shard described below)"),
+                          "records_total": n, "n_double": st["n_double"], "n_single": st["n_single"],
+                          "dup_records": st["n_dup_records"], "radix_passes": st["n_radix_passes"], "shard": shard_info},
+               "device_ms": st["ms_total"], "upload_s": upload_s, "route_s": route_s,
+               "pcie_inclusive_mrecords_s": (n if world == 1 else shard_info["n_order"]) / (upload_s + st["ms_total"] * 1e-3) / 1e6,
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": measured_traffic("k_radix_scatter<false, false, 4, false>") if n == 200_000_000 else None,
+                            "traffic": measured_traffic("k_radix_scatter<false, false, 4, false>") if n == 200_000_000 and world == 1 else None,
+                            "traffic_source": "offline rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in this run",
                             "kernel": "k_radix_scatter<false, false, 4, false> (record sort on packed coord<<32|arrival words, "
                                       f"{st1['n_scatter_records']} full-width launches per run)", "kernel_ms": ms_scatter_avg,
                             "kernel_ms_overlapped": ms_overlapped,

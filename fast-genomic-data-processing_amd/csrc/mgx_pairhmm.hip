@@ -33,10 +33,13 @@ using mgx::set_error;
 
 namespace {
 
-// Row classes: G = 16 lanes per pair with 1..12 rows per lane (reads up to 192 bases: the common
-// 100-151 bp short reads stay on the 4-pairs-per-wavefront shape), G = 64 with 4..16 rows per lane
-// beyond that (up to 1024 bases).
-constexpr int kG16MaxRPL = 12, kG64MinRPL = 4, kG64MaxRPL = 16;
+// Row classes: a read of R rows is owned by G lanes with RPL = ceil(R / G) rows each.  Few rows per lane waste
+// issue slots on the per-step overhead (3 DPP moves, the haplotype byte, loop control are paid per step, not per
+// cell), many lanes waste steps on fill/drain (G - 1 per pair) and lanes on padding (up to G - 1 rows), so short
+// reads take narrow groups: G = 4 up to 32 bases, G = 8 up to 64, G = 16 up to 192 (1..12 rows per lane: the
+// common 100-151 bp reads), G = 64 with 4..16 rows per lane beyond that (up to 1024 bases).
+constexpr int kNarrowMaxRPL = 8, kG16MaxRPL = 12, kG64MinRPL = 4, kG64MaxRPL = 16;
+constexpr int kMaxRowsG4 = 4 * kNarrowMaxRPL, kMaxRowsG8 = 8 * kNarrowMaxRPL;
 constexpr int kMaxRowsG16 = 16 * kG16MaxRPL;
 constexpr int kMaxRowsG64 = 64 * kG64MaxRPL;
 constexpr uint32_t kMaxLdsPerBlock = 64 * 1024;
@@ -70,6 +73,12 @@ struct mgx_pairhmm {
     int device = 0;
     unsigned flags = 0;
     hipStream_t compute = nullptr, copy = nullptr, d2h = nullptr;   // kernels | uploads | result downloads
+    // a batch with several read-length classes launches one kernel per class: they are dealt to the compute
+    // stream and these side streams so that the drain of one launch overlaps the body of the others
+    static constexpr int kAux = 3;
+    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr};
+    int n_streams = 1;
     float* d_ph2pr_f = nullptr; float* d_mm_f = nullptr; float* d_div3_f = nullptr; float* d_ratio_f = nullptr;
     double* d_ph2pr_d = nullptr; double* d_mm_d = nullptr; double* d_div3_d = nullptr; double* d_ratio_d = nullptr;
     float log10_initial_f = 0; double log10_initial_d = 0;
@@ -138,9 +147,12 @@ int upload(T** dst, const void* src, size_t bytes, hipStream_t s) {
     return 0;
 }
 
-// (G, RPL) class of a read of R rows; G = 0 if unsupported.
+// (G, RPL) class of a read of R rows; G = 0 if unsupported.  MGX_PAIRHMM_MIN_G=16 switches the narrow groups off.
 inline void shape_of(uint32_t R, int* G, int* RPL) {
-    if (R <= (uint32_t)kMaxRowsG16) { *G = 16; *RPL = (int)((R + 15) / 16); }
+    static const int min_g = [] { const char* e = getenv("MGX_PAIRHMM_MIN_G"); const int v = e ? atoi(e) : 4; return v; }();
+    if (R <= (uint32_t)kMaxRowsG4 && min_g <= 4) { *G = 4; *RPL = (int)((R + 3) / 4); }
+    else if (R <= (uint32_t)kMaxRowsG8 && min_g <= 8) { *G = 8; *RPL = (int)((R + 7) / 8); }
+    else if (R <= (uint32_t)kMaxRowsG16) { *G = 16; *RPL = (int)((R + 15) / 16); }
     else if (R <= (uint32_t)kMaxRowsG64) { *G = 64; *RPL = std::max(kG64MinRPL, (int)((R + 63) / 64)); }
     else { *G = 0; *RPL = 0; }
 }
@@ -150,10 +162,17 @@ inline uint32_t lds_bytes(const Bin& bin, bool f32) {
     const uint32_t etab = f32 ? (uint32_t)((bin.RPL + 1) / 2) * kNumCodes * 512u : 0u;
     return waves * etab + groups * bin.lds_stride;
 }
-constexpr int kBins = kG16MaxRPL + (kG64MaxRPL - kG64MinRPL + 1);
-inline int bin_index(int G, int RPL) { return G == 16 ? RPL - 1 : kG16MaxRPL + RPL - kG64MinRPL; }
+// bins in order of (G, RPL): [G=4: 1..8][G=8: 1..8][G=16: 1..12][G=64: 4..16]
+constexpr int kBinG8 = kNarrowMaxRPL, kBinG16 = 2 * kNarrowMaxRPL, kBinG64 = kBinG16 + kG16MaxRPL;
+constexpr int kBins = kBinG64 + (kG64MaxRPL - kG64MinRPL + 1);
+inline int bin_index(int G, int RPL) {
+    return G == 4 ? RPL - 1 : G == 8 ? kBinG8 + RPL - 1 : G == 16 ? kBinG16 + RPL - 1 : kBinG64 + RPL - kG64MinRPL;
+}
 inline void bin_shape(int k, Bin* b) {
-    if (k < kG16MaxRPL) { b->G = 16; b->RPL = k + 1; } else { b->G = 64; b->RPL = k - kG16MaxRPL + kG64MinRPL; }
+    if (k < kBinG8) { b->G = 4; b->RPL = k + 1; }
+    else if (k < kBinG16) { b->G = 8; b->RPL = k - kBinG8 + 1; }
+    else if (k < kBinG64) { b->G = 16; b->RPL = k - kBinG16 + 1; }
+    else { b->G = 64; b->RPL = k - kBinG64 + kG64MinRPL; }
     // the fp64 kernel keeps twice the registers per row: beyond 8 rows per lane of 16 it runs one
     // pair per wavefront instead
     if (b->G == 16 && b->RPL > 8) { b->Gd = 64; b->RPLd = (16 * b->RPL + 63) / 64; } else { b->Gd = b->G; b->RPLd = b->RPL; }
@@ -182,7 +201,7 @@ int finalize_bin(Bin& bin, int n_cu) {
 void merge_small_bins(uint64_t (&count)[kBins], int (&remap)[kBins]) {
     for (int k = 0; k < kBins; ++k) remap[k] = k;
     for (int k = 0; k + 1 < kBins; ++k) {
-        if (k + 1 == kG16MaxRPL) continue;                      // never across the group-width boundary
+        if (k + 1 == kBinG8 || k + 1 == kBinG16 || k + 1 == kBinG64) continue;   // never across a group-width boundary
         if (count[k] && count[k] < kMergeBelow) { count[k + 1] += count[k]; count[k] = 0; remap[k] = k + 1; }
     }
     for (int k = 0; k < kBins; ++k) { int t = k; while (remap[t] != t) t = remap[t]; remap[k] = t; }
@@ -299,6 +318,20 @@ int mgx_pairhmm_create(int device, unsigned flags, mgx_pairhmm_t** out) {
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
+    {
+        const unsigned pat = (flags >> 8) & 0xFFu;
+        const char* e = getenv("MGX_PAIRHMM_STREAMS");
+        // default 1: measured on an MI355X (profiles/r02_pairhmm_shapes.txt) concurrent class kernels on several
+        // streams were SLOWER than one after the other (ragged 1 M test cases: 4163 vs 4227 GCUPS, reads of 33-64
+        // bases 3764 vs 4371) -- the launches compete for the same CUs instead of filling each other's drain
+        c->n_streams = e ? std::max(1, std::min(1 + mgx_pairhmm::kAux, atoi(e))) : 1;
+        if (pat != 0 && pat != 0xFFu) c->n_streams = 1;          // a CU-masked context keeps to its masked stream
+        for (int a = 0; a + 1 < c->n_streams; ++a) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    }
     const auto& tf = mgx::tables<float>();
     const auto& td = mgx::tables<double>();
     int rc;
@@ -327,6 +360,8 @@ void mgx_pairhmm_destroy(mgx_pairhmm_t* c) {
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
     if (c->d2h) (void)hipStreamDestroy(c->d2h);
+    for (int a = 0; a < mgx_pairhmm::kAux; ++a) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
 
@@ -380,7 +415,7 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
         haps[h] = SeqRef{in->hap_off[h], (uint32_t)H, (uint32_t)h};
         sumH += H; max_h = std::max<uint32_t>(max_h, (uint32_t)H);
     }
-    std::stable_sort(haps.begin(), haps.end(), [](const SeqRef& a, const SeqRef& b2) { return a.len < b2.len; });
+    std::stable_sort(haps.begin(), haps.end(), [](const SeqRef& a, const SeqRef& b2) { return a.len > b2.len; });
     int remap[kBins];
     merge_small_bins(count, remap);
     uint64_t reads_in[kBins] = {0}, rstart[kBins + 1] = {0};
@@ -515,7 +550,7 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
                 haps[h_at + h] = SeqRef{hb + (in.hap_off[h] - in.hap_off[0]), (uint32_t)H, (uint32_t)h};
                 max_h = std::max<uint32_t>(max_h, (uint32_t)H);
             }
-            std::stable_sort(haps.begin() + h_at, haps.begin() + h_at + in.n_haps, [](const SeqRef& a, const SeqRef& b2) { return a.len < b2.len; });
+            std::stable_sort(haps.begin() + h_at, haps.begin() + h_at + in.n_haps, [](const SeqRef& a, const SeqRef& b2) { return a.len > b2.len; });
             for (uint64_t r = 0; r < in.n_reads; ++r) {
                 const uint64_t Rl = in.read_off[r + 1] - in.read_off[r];
                 if (Rl == 0) { set_error("region %u: read %llu is empty", g, (unsigned long long)r); return -EINVAL; }
@@ -753,8 +788,9 @@ int create_pairs(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const mgx::Pac
     if (!staged) b->host_jobs.resize(n);
     Job* jobs = staged ? (Job*)(b->slab.pin + o_jobs) : b->host_jobs.data();
     {
-        // key = (bin, H): counting sort on H inside each bin keeps the wavefront's groups
-        // (consecutive jobs) at near-equal step counts.
+        // key = (bin, H descending): counting sort on H inside each bin keeps the wavefront's groups
+        // (consecutive jobs) at near-equal step counts, and longest first means the last workgroups of a
+        // launch -- its drain -- are the shortest jobs.
         std::vector<uint64_t> bin_start(kBins + 1, 0);
         for (int k = 0; k < kBins; ++k) bin_start[k + 1] = bin_start[k] + count[k];
         std::vector<std::vector<uint32_t>> hist(kBins);
@@ -762,7 +798,7 @@ int create_pairs(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const mgx::Pac
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t h = ph[i];
             const uint32_t H = (uint32_t)(hoff[h + 1] - hoff[h]);
-            hist[bin_of[i]][H + 1]++;
+            hist[bin_of[i]][(max_h - H) + 1]++;
         }
         for (int k = 0; k < kBins; ++k)
             for (size_t x = 1; x < hist[k].size(); ++x) hist[k][x] += hist[k][x - 1];
@@ -771,7 +807,7 @@ int create_pairs(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const mgx::Pac
             const uint32_t R = (uint32_t)(roff[r + 1] - roff[r]);
             const uint32_t H = (uint32_t)(hoff[h + 1] - hoff[h]);
             const int k = (int)bin_of[i];
-            Job& jb = jobs[bin_start[k] + hist[k][H]++];
+            Job& jb = jobs[bin_start[k] + hist[k][max_h - H]++];
             jb.read_off = roff[r]; jb.hap_off = hoff[h];
             jb.R = R; jb.H = H; jb.pair = (uint32_t)i; jb.pad_ = 0;
         }
@@ -857,37 +893,87 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     if (b->uploaded) HIP_TRY(hipStreamWaitEvent(s, b->uploaded, 0));
     HIP_TRY(hipMemsetAsync(b->d_rerun_count, 0, 64 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(b->d_used, 0, b->n_pairs, s));
+    // largest class first, classes dealt round-robin to the compute stream and the side streams
+    std::vector<size_t> order(b->bins.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return b->bins[x].cells > b->bins[y].cells; });
+    const int n_str = (int)std::min<size_t>((size_t)c->n_streams, b->bins.size());
+    if (n_str > 1) {
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        for (int q = 0; q + 1 < n_str; ++q) HIP_TRY(hipStreamWaitEvent(c->aux[q], c->ev_fork, 0));
+    }
+    // Re-runs in double precision: the "narrow" classes (at most 16 lanes x 8 rows: every read up to 128 bases) append
+    // to ONE list (their jobs are a prefix of the job array) that ONE fp64 launch of the 16 x RPLd shape processes --
+    // a test case's value does not depend on the shape that computes it; wider classes keep a list and a launch each.
+    auto narrow = [](const Bin& bn) { return bn.G <= 16 && bn.RPL <= kNarrowMaxRPL; };
+    uint32_t n_narrow_jobs = 0, narrow_max_h = 0, narrow_rows = 0;
+    size_t first_narrow = b->bins.size();
     for (size_t k = 0; k < b->bins.size(); ++k) {
+        const Bin& bn = b->bins[k];
+        if (!narrow(bn)) continue;
+        if (first_narrow == b->bins.size()) first_narrow = k;
+        n_narrow_jobs = std::max(n_narrow_jobs, bn.job_begin + bn.job_count);
+        narrow_max_h = std::max(narrow_max_h, bn.max_h);
+        narrow_rows = std::max(narrow_rows, (uint32_t)(bn.G * bn.RPL));
+    }
+    constexpr int kSharedCount = 63;                       // counter slot of the shared list
+    KernelArgs base{};
+    base.jobs = b->d_jobs;
+    base.bases = b->d_bases; base.qual = b->d_qual; base.ins = b->d_ins; base.del = b->d_del;
+    base.gcp = b->d_gcp; base.hap_bases = b->d_hap;
+    base.out_log10 = b->d_out; base.used_f64 = b->d_used;
+    base.log10_initial_f = c->log10_initial_f;
+    base.log10_initial_d = c->log10_initial_d;
+    auto launch_f64 = [&](KernelArgs a, int Gd, int RPLd, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t sk) -> int {
+        a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d; a.ph2pr_div3 = c->d_div3_d; a.gap_ratio = c->d_ratio_d;
+        KernelFn f = pick_kernel<double>(Gd, RPLd);
+        if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", Gd, RPLd); return -ENOSYS; }
+        hipLaunchKernelGGL(f, dim3(grid), dim3(block), lds, sk, a);
+        return 0;
+    };
+    for (size_t at = 0; at < order.size(); ++at) {
+        const size_t k = order[at];
         const Bin& bin = b->bins[k];
-        KernelArgs a{};
-        a.jobs = b->d_jobs + bin.job_begin;
-        a.bases = b->d_bases; a.qual = b->d_qual; a.ins = b->d_ins; a.del = b->d_del;
-        a.gcp = b->d_gcp; a.hap_bases = b->d_hap;
-        a.out_log10 = b->d_out; a.used_f64 = b->d_used;
-        a.rerun_list = b->d_rerun_list + bin.job_begin;
-        a.rerun_count = b->d_rerun_count + k;
+        hipStream_t sk = (int)(at % (size_t)n_str) == 0 ? s : c->aux[at % (size_t)n_str - 1];
+        const bool shared = narrow(bin) && !force_f64 && n_str == 1;
+        KernelArgs a = base;
+        a.rerun_list = shared ? b->d_rerun_list : b->d_rerun_list + bin.job_begin;
+        a.rerun_count = b->d_rerun_count + (shared ? kSharedCount : (int)k);
         a.lds_stride = bin.lds_stride;
-        a.log10_initial_f = c->log10_initial_f;
-        a.log10_initial_d = c->log10_initial_d;
+        a.job_first = bin.job_begin;
         if (!force_f64) {
             a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count;
             a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f; a.ph2pr_div3 = c->d_div3_f; a.gap_ratio = c->d_ratio_f;
             KernelFn f = pick_kernel<float>(bin.G, bin.RPL);
             if (!f) { set_error("no fp32 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
-            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 0], s));
-            hipLaunchKernelGGL(f, dim3(bin.grid_f32), dim3(bin.block), lds_bytes(bin, true), s, a);
-            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 1], s));
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 0], sk));
+            hipLaunchKernelGGL(f, dim3(bin.grid_f32), dim3(bin.block), lds_bytes(bin, true), sk, a);
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 1], sk));
         }
-        {
-            a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d; a.ph2pr_div3 = c->d_div3_d; a.gap_ratio = c->d_ratio_d;
+        const bool books_shared = shared && k == first_narrow;      // the shared launch is booked on the first narrow class
+        if (timing && !books_shared) HIP_TRY(hipEventRecord(ev[4 * k + 2], sk));
+        if (!shared) {
             if (force_f64) { a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count; }
-            else { a.job_list = b->d_rerun_list + bin.job_begin; a.n_dyn = b->d_rerun_count + k; a.n_static = 0; }
-            KernelFn f = pick_kernel<double>(bin.Gd, bin.RPLd);
-            if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", bin.Gd, bin.RPLd); return -ENOSYS; }
-            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 2], s));
-            hipLaunchKernelGGL(f, dim3(force_f64 ? bin.grid_f64_all : bin.grid_f64), dim3(bin.block), lds_bytes(bin, false), s, a);
-            if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 3], s));
+            else { a.job_list = a.rerun_list; a.n_dyn = a.rerun_count; a.n_static = 0; }
+            const int rc = launch_f64(a, bin.Gd, bin.RPLd, force_f64 ? bin.grid_f64_all : bin.grid_f64, bin.block, lds_bytes(bin, false), sk);
+            if (rc) return rc;
         }
+        if (timing && !books_shared) HIP_TRY(hipEventRecord(ev[4 * k + 3], sk));
+    }
+    if (n_narrow_jobs && !force_f64 && n_str == 1) {
+        KernelArgs a = base;
+        a.job_list = b->d_rerun_list; a.n_dyn = b->d_rerun_count + kSharedCount; a.n_static = 0; a.job_first = 0;
+        a.lds_stride = (narrow_max_h + 2u * 16u + 8u + 15u) & ~15u;
+        const int RPLd = (int)((narrow_rows + 15) / 16);
+        const uint32_t grid = std::min<uint32_t>((n_narrow_jobs + 3) / 4, (uint32_t)c->n_cu * 8u);
+        if (timing) HIP_TRY(hipEventRecord(ev[4 * first_narrow + 2], s));
+        const int rc = launch_f64(a, 16, RPLd, grid, 64, 4u * a.lds_stride, s);
+        if (rc) return rc;
+        if (timing) HIP_TRY(hipEventRecord(ev[4 * first_narrow + 3], s));
+    }
+    for (int q = 0; q + 1 < n_str; ++q) {
+        HIP_TRY(hipEventRecord(c->ev_join[q], c->aux[q]));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_join[q], 0));
     }
     if (b->has_model && b->d_row_off)
         hipLaunchKernelGGL(pairhmm_normalize_filter_rows, dim3((b->n_reads + 3) / 4), dim3(256), 0, s, b->d_out, b->d_read_len,
@@ -923,6 +1009,7 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, mgx_pairhm
         std::vector<uint32_t> cnt(64);
         HIP_TRY(hipMemcpy(cnt.data(), b->d_rerun_count, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (size_t k = 0; k < b->bins.size(); ++k) st.n_rerun_f64 += force_f64 ? b->bins[k].job_count : cnt[k];
+        if (!force_f64) st.n_rerun_f64 += cnt[63];          // the narrow classes' shared list
     }
     st.ms_f32 = st.ms_f64 = st.ms_f32_dominant = 0;
     st.dominant_cells = st.dominant_alg_bytes = 0;
@@ -963,6 +1050,19 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, mgx_pairhm
     return 0;
 }
 
+namespace {
+// Results of a batch that has been run, into its pinned mirror (staged batches): waits for this batch's last
+// kernel only.  Downloads run on their own stream, so the results of batch k do not queue behind the kernels of
+// batch k+1 that were enqueued in the meantime.
+int fetch_results(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, size_t bytes) {
+    hipStream_t s = c->d2h;
+    if (b->done) HIP_TRY(hipStreamWaitEvent(s, b->done, 0));
+    HIP_TRY(hipMemcpyAsync(b->slab.pin + b->o_out, b->d_out, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+}  // namespace
+
 int mgx_pairhmm_batch_results(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, double* out_log10,
                               uint8_t* used_f64) {
     if (!c || !b) { set_error("ctx/batch is NULL"); return -EINVAL; }
@@ -970,19 +1070,15 @@ int mgx_pairhmm_batch_results(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, double* 
     HIP_TRY(hipSetDevice(c->device));
     if (b->n_pairs == 0) return 0;
     if (!out_log10) { set_error("out_log10 is NULL"); return -EINVAL; }
-    // downloads run on their own stream behind this batch's last kernel, so the results of batch k do not
-    // queue behind the kernels of batch k+1 that were enqueued in the meantime
-    hipStream_t s = c->d2h;
-    if (b->done) HIP_TRY(hipStreamWaitEvent(s, b->done, 0));
     if (b->slab.pin) {
-        uint8_t* pin = b->slab.pin + b->o_out;
-        const size_t bytes = used_f64 ? b->result_bytes : b->n_pairs * sizeof(double);
-        HIP_TRY(hipMemcpyAsync(pin, b->d_out, bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        memcpy(out_log10, pin, b->n_pairs * sizeof(double));
+        const int rc = fetch_results(c, b, used_f64 ? b->o_used + b->n_pairs - b->o_out : b->n_pairs * sizeof(double));
+        if (rc) return rc;
+        memcpy(out_log10, b->slab.pin + b->o_out, b->n_pairs * sizeof(double));
         if (used_f64) memcpy(used_f64, b->slab.pin + b->o_used, b->n_pairs);
         return 0;
     }
+    hipStream_t s = c->d2h;
+    if (b->done) HIP_TRY(hipStreamWaitEvent(s, b->done, 0));
     HIP_TRY(hipMemcpyAsync(out_log10, b->d_out, b->n_pairs * sizeof(double), hipMemcpyDeviceToHost, s));
     if (used_f64) HIP_TRY(hipMemcpyAsync(used_f64, b->d_used, b->n_pairs, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1092,15 +1188,15 @@ int mgx_pairhmm_compute_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_
     if (b->n_pairs == 0) return 0;
     mgx_pairhmm_batch_t* raw = b.release();
     rc = mgx_pairhmm_batch_run(c, raw);
-    std::vector<double> all;
-    if (!rc) { all.resize(raw->n_pairs); rc = mgx_pairhmm_batch_results(c, raw, all.data(), nullptr); }
+    if (!rc) rc = fetch_results(c, raw, raw->n_pairs * sizeof(double));
+    if (!rc) {
+        const double* all = (const double*)(raw->slab.pin + raw->o_out);
+        for (uint32_t g = 0; g < n_regions; ++g)
+            if (base[g + 1] > base[g]) memcpy(out_log10[g], all + base[g], (base[g + 1] - base[g]) * sizeof(double));
+    }
     mgx_pairhmm_batch_destroy(c, raw);
-    if (rc) return rc;
-    for (uint32_t g = 0; g < n_regions; ++g)
-        if (base[g + 1] > base[g]) memcpy(out_log10[g], all.data() + base[g], (base[g + 1] - base[g]) * sizeof(double));
-    return 0;
+    return rc;
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Host work queue (BASELINE.json configs[2]).  The reference's worker threads pull the next active
@@ -1128,10 +1224,14 @@ struct mgx_pairhmm_queue {
 namespace {
 
 struct QueueRun {
-    const mgx_pairhmm_input_t* in = nullptr;
+    const mgx_pairhmm_input_t* in = nullptr;      // pair-stream mode: one long stream, batches are test-case ranges
     uint64_t lo = 0, hi = 0, n_batches = 0;
     double* out = nullptr;
     uint8_t* used = nullptr;
+    // region mode (row F1): many active regions in the cross-product form, batches are runs of whole regions
+    const mgx_pairhmm_input_t* regions = nullptr;
+    double* const* region_out = nullptr;
+    std::vector<uint32_t> chunk;                   // [n_batches + 1] region index boundaries
     std::atomic<uint64_t> next{0};
     std::atomic<int> failed{0};
     std::mutex err_mu;
@@ -1147,7 +1247,7 @@ struct QueueRun {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void queue_lane(mgx_pairhmm_queue* q, mgx_pairhmm_queue::Lane* ln, QueueRun* run) {
-    struct Slot { mgx_pairhmm_batch* b = nullptr; uint64_t lo = 0; };
+    struct Slot { mgx_pairhmm_batch* b = nullptr; uint64_t lo = 0; uint32_t g0 = 0, g1 = 0; std::vector<uint64_t> base; };
     std::vector<Slot> slots(q->depth);
     mgx::PackPlan plan;
     mgx_pairhmm* c = ln->ctx;
@@ -1156,10 +1256,23 @@ void queue_lane(mgx_pairhmm_queue* q, mgx_pairhmm_queue::Lane* ln, QueueRun* run
         if (!sl.b) return;
         const double t0 = now_s();
         if (!run->failed.load()) {
-            const uint64_t at = sl.lo - run->lo;
-            const int rc = mgx_pairhmm_batch_results(c, sl.b, run->out + at, run->used ? run->used + at : nullptr);
+            int rc = 0;
+            if (run->regions) {
+                rc = fetch_results(c, sl.b, sl.b->n_pairs * sizeof(double));
+                if (!rc) {
+                    const double* all = (const double*)(sl.b->slab.pin + sl.b->o_out);
+                    for (uint32_t g = sl.g0; g < sl.g1; ++g) {
+                        const uint64_t a = sl.base[g - sl.g0], e = sl.base[g - sl.g0 + 1];
+                        if (e > a) memcpy(run->region_out[g], all + a, (e - a) * sizeof(double));
+                    }
+                }
+                ln->bytes_d2h += sl.b->n_pairs * 8;
+            } else {
+                const uint64_t at = sl.lo - run->lo;
+                rc = mgx_pairhmm_batch_results(c, sl.b, run->out + at, run->used ? run->used + at : nullptr);
+                ln->bytes_d2h += sl.b->n_pairs * (run->used ? 9 : 8);
+            }
             if (rc) run->fail(rc);
-            ln->bytes_d2h += sl.b->n_pairs * (run->used ? 9 : 8);
         }
         mgx_pairhmm_batch_destroy(c, sl.b);
         sl.b = nullptr;
@@ -1172,19 +1285,47 @@ void queue_lane(mgx_pairhmm_queue* q, mgx_pairhmm_queue::Lane* ln, QueueRun* run
         Slot& sl = slots[turn++ % slots.size()];
         retire(sl);
         if (run->failed.load()) break;
-        const uint64_t lo = run->lo + k * q->batch_pairs, hi = std::min(run->hi, lo + q->batch_pairs);
         const double t0 = now_s();
-        const uint64_t bad = mgx::pack_plan(run->in, lo, hi, &plan);
-        if (bad) { set_error("test case %llu: index out of range", (unsigned long long)(lo + bad - 1)); run->fail(-EINVAL); break; }
         BatchPtr b = new_batch();
-        int rc = b ? create_pairs(c, run->in, &plan, b.get()) : -ENOMEM;
+        int rc = b ? 0 : -ENOMEM;
+        if (!rc && run->regions) {
+            sl.g0 = run->chunk[k]; sl.g1 = run->chunk[k + 1];
+            rc = create_cross_multi(c, sl.g1 - sl.g0, run->regions + sl.g0, b.get(), &sl.base);
+        } else if (!rc) {
+            sl.lo = run->lo + k * q->batch_pairs;
+            const uint64_t hi = std::min(run->hi, sl.lo + q->batch_pairs);
+            const uint64_t bad = mgx::pack_plan(run->in, sl.lo, hi, &plan);
+            if (bad) { set_error("test case %llu: index out of range", (unsigned long long)(sl.lo + bad - 1)); run->fail(-EINVAL); break; }
+            rc = create_pairs(c, run->in, &plan, b.get());
+        }
         ln->pack_s += now_s() - t0;
-        if (!rc) rc = mgx_pairhmm_batch_run(c, b.get());
+        if (!rc && b->n_pairs) rc = mgx_pairhmm_batch_run(c, b.get());
         if (rc) { run->fail(rc); break; }
+        if (!b->n_pairs) continue;                  // a chunk of empty regions
         ln->batches++; ln->bytes_h2d += b->in_bytes; ln->cells += b->stats.cells;
-        sl.b = b.release(); sl.lo = lo;
+        sl.b = b.release();
     }
     for (size_t j = 0; j < slots.size(); ++j) retire(slots[(turn + j) % slots.size()]);    // oldest first
+}
+
+int queue_execute(mgx_pairhmm_queue* q, QueueRun& run, uint64_t n_pairs) {
+    for (auto& ln : q->lanes) { ln.pack_s = ln.wait_s = 0; ln.batches = ln.bytes_h2d = ln.bytes_d2h = ln.cells = 0; }
+    const double t0 = now_s();
+    const size_t n_thr = (size_t)std::min<uint64_t>(q->lanes.size(), run.n_batches);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < n_thr; ++i) th.emplace_back(queue_lane, q, &q->lanes[i], &run);
+    queue_lane(q, &q->lanes[0], &run);               // the caller's thread is lane 0
+    for (auto& t : th) t.join();
+    q->stats.seconds = now_s() - t0;
+    q->stats.n_pairs = n_pairs;
+    q->stats.n_batches = run.n_batches;
+    for (auto& ln : q->lanes) {
+        q->stats.cells += ln.cells; q->stats.bytes_h2d += ln.bytes_h2d; q->stats.bytes_d2h += ln.bytes_d2h;
+        q->stats.pack_seconds += ln.pack_s; q->stats.wait_seconds += ln.wait_s;
+        q->stats.batches_per_device[ln.dev_slot] += ln.batches;
+    }
+    if (run.rc) { set_error("%s", run.err.c_str()); return run.rc; }
+    return 0;
 }
 
 }  // namespace
@@ -1236,23 +1377,31 @@ int mgx_pairhmm_queue_run_range(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_
     QueueRun run;
     run.in = in; run.lo = pair_begin; run.hi = pair_end; run.out = out_log10; run.used = used_f64;
     run.n_batches = (pair_end - pair_begin + q->batch_pairs - 1) / q->batch_pairs;
-    for (auto& ln : q->lanes) { ln.pack_s = ln.wait_s = 0; ln.batches = ln.bytes_h2d = ln.bytes_d2h = ln.cells = 0; }
-    const double t0 = now_s();
-    const size_t n_thr = (size_t)std::min<uint64_t>(q->lanes.size(), run.n_batches);
-    std::vector<std::thread> th;
-    for (size_t i = 1; i < n_thr; ++i) th.emplace_back(queue_lane, q, &q->lanes[i], &run);
-    queue_lane(q, &q->lanes[0], &run);               // the caller's thread is lane 0
-    for (auto& t : th) t.join();
-    q->stats.seconds = now_s() - t0;
-    q->stats.n_pairs = pair_end - pair_begin;
-    q->stats.n_batches = run.n_batches;
-    for (auto& ln : q->lanes) {
-        q->stats.cells += ln.cells; q->stats.bytes_h2d += ln.bytes_h2d; q->stats.bytes_d2h += ln.bytes_d2h;
-        q->stats.pack_seconds += ln.pack_s; q->stats.wait_seconds += ln.wait_s;
-        q->stats.batches_per_device[ln.dev_slot] += ln.batches;
+    return queue_execute(q, run, pair_end - pair_begin);
+}
+
+int mgx_pairhmm_queue_run_regions(mgx_pairhmm_queue_t* q, uint32_t n_regions, const mgx_pairhmm_input_t* regions, double* const* out_log10) {
+    if (!q || (n_regions && (!regions || !out_log10))) { set_error("NULL argument"); return -EINVAL; }
+    q->stats = mgx_pairhmm_queue_stats_t{};
+    q->stats.n_lanes = (uint32_t)q->lanes.size();
+    QueueRun run;
+    run.regions = regions; run.region_out = out_log10;
+    // batches are runs of whole regions holding about batch_pairs test cases
+    uint64_t total = 0, in_chunk = 0;
+    run.chunk.push_back(0);
+    for (uint32_t g = 0; g < n_regions; ++g) {
+        int rc = validate(&regions[g]);
+        if (rc) return rc;
+        if (regions[g].pair_read || regions[g].pair_hap) { set_error("region %u: regions are given in the cross-product form (pair arrays NULL)", g); return -EINVAL; }
+        const uint64_t n = regions[g].n_reads * regions[g].n_haps;
+        if (n && !out_log10[g]) { set_error("region %u: output pointer is NULL", g); return -EINVAL; }
+        if (in_chunk && in_chunk + n > q->batch_pairs) { run.chunk.push_back(g); in_chunk = 0; }
+        in_chunk += n; total += n;
     }
-    if (run.rc) { set_error("%s", run.err.c_str()); return run.rc; }
-    return 0;
+    if (n_regions) run.chunk.push_back(n_regions);
+    run.n_batches = run.chunk.size() - 1;
+    if (total == 0) return 0;
+    return queue_execute(q, run, total);
 }
 
 int mgx_pairhmm_queue_run(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_t* in, double* out_log10, uint8_t* used_f64) {

@@ -265,6 +265,22 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
     }
 }
 
+// Upload wire format: whenever a piece's coordinates and 5' ends all fit 32 bits (always, unless a 5' end wrapped
+// below zero or L >= 2^32) the staging threads squeeze the 32-byte records to 24 bytes on their way into the pinned
+// buffer -- a quarter fewer bytes over PCIe, the link being what an upload waits for -- and this kernel restores
+// the 32-byte layout in HBM right behind the copy.
+struct Wire24 { u32 coord, prime5, mate; uint16_t flag, score, tile, x, y, pad_; };
+static_assert(sizeof(Wire24) == 24, "wire record is 24 bytes");
+__global__ __launch_bounds__(256) void k_expand24(const Wire24* __restrict__ src, mgx_rec_t* __restrict__ dst, u32 n) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Wire24 w = src[i];
+    mgx_rec_t r;
+    r.coord = w.coord; r.prime5 = w.prime5; r.mate = w.mate; r.flag = w.flag; r.score = w.score;
+    r.tile = w.tile; r.x = w.x; r.y = w.y; r.pad_ = 0;
+    dst[i] = r;
+}
+
 // Sharded input (mgx_sortdedup_upload_shard): the records a shard ORDERS are not the records it MARKS, so the
 // coordinate keys come from the routed (coordinate, global arrival index) arrays instead of the build kernel.
 __global__ __launch_bounds__(256) void k_order_keys(const u64* __restrict__ coord, const u32* __restrict__ arrival, u32 n,
@@ -305,13 +321,14 @@ __global__ __launch_bounds__(256) void k_or_marks(const u64* __restrict__ marks,
 // ---------------------------------------------------------------------------------------------
 // radix sort pass: histogram -> column scan -> ranked scatter
 // ---------------------------------------------------------------------------------------------
+template <int TILE>
 __global__ __launch_bounds__(256) void k_radix_hist(const u64* __restrict__ keys, u32 n, int shift, u32* __restrict__ hist) {
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const u32 base = blockIdx.x * kTile;
+    const u32 base = blockIdx.x * TILE;
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
+    for (int k = 0; k < TILE / 256; ++k) {
         const u32 i = base + k * 256 + threadIdx.x;
         if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & 255u], 1u);
     }
@@ -391,7 +408,8 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sm) {
     return base + incl - v;
 }
 
-// One 4096-key tile per workgroup of WAVES wavefronts; every wavefront ranks a contiguous slice.
+// One tile of WAVES x 1024 keys per workgroup of WAVES wavefronts; every wavefront ranks a contiguous slice.
+// (8 wavefronts = 8192-key tiles double the run a digit leaves the tile with, but measured slower: see radix_sort.)
 // LOW32: last pass of the packed record sort -- only the low half of every key (the arrival index)
 // is stored, to pout32, which makes the sorted keys themselves unnecessary.
 template <bool HAS_P64, bool HAS_P32, int WAVES, bool LOW32 = false>
@@ -400,9 +418,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restr
                                                               const u32* __restrict__ pin32, u32* __restrict__ pout32,
                                                               u32 n, int shift, const u32* __restrict__ goff, u32 n_tiles, int xcd_order) {
     constexpr int T = WAVES * 64;           // threads
-    constexpr int ITEMS = kTile / T;        // keys per thread
+    constexpr int ITEMS = kItems;           // keys per thread
+    constexpr int kTile = T * ITEMS;        // keys per workgroup: 4096 with 4 wavefronts, 8192 with 8
     constexpr int SLICE = kTile / WAVES;    // keys per wavefront
-    __shared__ u64 sbuf[kTile];             // 32 KB exchange buffer (keys, then payloads)
+    __shared__ u64 sbuf[kTile];             // exchange buffer (keys, then payloads): 32 KB / 64 KB
     __shared__ u32 wcnt[WAVES][256];        // per wavefront and digit: running count, later the slot base
     __shared__ u32 gdelta[256];             // global offset of the digit's run minus its tile-local start
     __shared__ u32 sm[WAVES];
@@ -1015,8 +1034,11 @@ struct mgx_sortdedup {
     bool sharded = false;
     u64* d_ocoord = nullptr; u32* d_oarr = nullptr; size_t order_cap = 0;   // a shard's ordering half as uploaded
     u64* d_marks = nullptr; size_t marks_cap = 0; u32 n_marks = 0;          // indicator marks routed from other shards
-    size_t cap = 0;                        // record capacity of the buffers below
-    mgx_rec_t* d_recs = nullptr;
+    size_t cap = 0;                        // record capacity of the work buffers below
+    mgx_rec_t* d_recs = nullptr; size_t recs_cap = 0;      // the uploaded records (grown on demand by a streamed upload)
+    void* d_wire[2] = {nullptr, nullptr};  // device side of the staging buffers: compact 24-byte records before expansion
+    uint64_t up_L = 0, up_high = 0;        // streamed upload in progress: reference length, highest record index seen + 1
+    bool uploading = false;
     u64 *d_ckey[2] = {nullptr, nullptr}; u32* d_cval[2] = {nullptr, nullptr};
     u64 *d_k1[2] = {nullptr, nullptr}, *d_k2[2] = {nullptr, nullptr}; u32* d_prec[2] = {nullptr, nullptr};
     u64* d_sk1[2] = {nullptr, nullptr}; u32* d_srec[2] = {nullptr, nullptr};
@@ -1045,6 +1067,7 @@ struct mgx_sortdedup {
     bool ran = false;
     bool near_by_position = true;          // near pairs sorted on record 1's 5' end only (MGX_SORTDEDUP_NEAR_EXACT=1: six-pass sort)
     bool finished = false;                 // the results of the last run have been checked for the fallback
+    int wide_tiles = -1;                   // MGX_SORTDEDUP_WIDE_TILES=1: 8192-key scatter tiles (measured slower; default 4096)
     int xcd_order = 1;                     // scatter tiles walk each XCD's contiguous range (MGX_SORTDEDUP_XCD_ORDER=0: plain)
     Scalars sc{};
     mgx_sortdedup_stats_t stats{};
@@ -1055,7 +1078,6 @@ namespace {
 constexpr size_t kPinnedChunk = 64u << 20;
 
 void free_buffers(mgx_sortdedup* c) {
-    (void)hipFree(c->d_recs); c->d_recs = nullptr;
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(c->d_ckey[i]); (void)hipFree(c->d_cval[i]); (void)hipFree(c->d_k1[i]); (void)hipFree(c->d_k2[i]);
         (void)hipFree(c->d_prec[i]); (void)hipFree(c->d_sk1[i]); (void)hipFree(c->d_srec[i]);
@@ -1080,7 +1102,6 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
     int rc = 0;
     const size_t half = n / 2 + 1;
     const size_t n_tiles = (n + kTile - 1) / kTile + 1;
-    rc |= dalloc(&c->d_recs, n);
     for (int i = 0; i < 2 && !rc; ++i) {
         rc |= dalloc(&c->d_ckey[i], n); rc |= dalloc(&c->d_cval[i], n);
         rc |= dalloc(&c->d_k1[i], half); rc |= dalloc(&c->d_k2[i], half); rc |= dalloc(&c->d_prec[i], half);
@@ -1101,35 +1122,37 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
 
 // one stable LSD radix sort of (key, [p64], p32) over `bits` low bits of the key
 // buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
-int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q, u64* key[2], u64* p64[2], u32* p32[2], u32 n,
-               int first_shift, int bits, int* cur, u32* low32_out = nullptr, bool* low32_done = nullptr) {
+template <int WAVES>
+int radix_sort_w(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q, u64* key[2], u64* p64[2], u32* p32[2], u32 n,
+                 int first_shift, int bits, int* cur, u32* low32_out, bool* low32_done) {
+    constexpr int TILE = WAVES * 64 * kItems;
     if (low32_done) *low32_done = false;
     if (n == 0) return 0;
-    const u32 n_tiles = (n + kTile - 1) / kTile;
+    const u32 n_tiles = (n + TILE - 1) / TILE;
     const u32 n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
     for (int shift = first_shift; shift < first_shift + bits; shift += 8) {
         const int in = *cur, out = in ^ 1;
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, q.hist);
+        hipLaunchKernelGGL(k_radix_hist<TILE>, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, q.hist);
         hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
         hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, s, q.chunk, n_chunks);
         hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
         const bool timing = c->ev_used + 2 <= c->ev_scatter.size();
         if (timing) HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used], s));
         if (p64 && !p32)
-            hipLaunchKernelGGL((k_radix_scatter<true, false, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], p64[in], p64[out],
+            hipLaunchKernelGGL((k_radix_scatter<true, false, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], p64[in], p64[out],
                                (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist, n_tiles, c->xcd_order);
         else if (p64)
-            hipLaunchKernelGGL((k_radix_scatter<true, true, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], p64[in], p64[out],
+            hipLaunchKernelGGL((k_radix_scatter<true, true, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], p64[in], p64[out],
                                p32[in], p32[out], n, shift, q.hist, n_tiles, c->xcd_order);
         else if (p32)
-            hipLaunchKernelGGL((k_radix_scatter<false, true, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
+            hipLaunchKernelGGL((k_radix_scatter<false, true, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], (const u64*)nullptr,
                                (u64*)nullptr, p32[in], p32[out], n, shift, q.hist, n_tiles, c->xcd_order);
         else if (low32_out && shift + 8 >= first_shift + bits) {
-            hipLaunchKernelGGL((k_radix_scatter<false, false, kScatterWaves, true>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
+            hipLaunchKernelGGL((k_radix_scatter<false, false, WAVES, true>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], (const u64*)nullptr,
                                (u64*)nullptr, (const u32*)nullptr, low32_out, n, shift, q.hist, n_tiles, c->xcd_order);
             if (low32_done) *low32_done = true;
         } else
-            hipLaunchKernelGGL((k_radix_scatter<false, false, kScatterWaves>), dim3(n_tiles), dim3(kScatterWaves * 64), 0, s, key[in], key[out], (const u64*)nullptr,
+            hipLaunchKernelGGL((k_radix_scatter<false, false, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], (const u64*)nullptr,
                                (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist, n_tiles, c->xcd_order);
         if (timing) { HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used + 1], s)); c->ev_used += 2; }
         c->scatter_bytes += (uint64_t)n * 2 * (8 + (p32 ? 4 : 0) + (p64 ? 8 : 0));
@@ -1139,6 +1162,18 @@ int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q,
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// one stable LSD radix sort of (key, [p64], p32) over `bits` low bits of the key
+// buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
+int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q, u64* key[2], u64* p64[2], u32* p32[2], u32 n,
+               int first_shift, int bits, int* cur, u32* low32_out = nullptr, bool* low32_done = nullptr) {
+    // 8192-key tiles (MGX_SORTDEDUP_WIDE_TILES=1) were meant to double the payload run a digit leaves the tile with;
+    // measured on an MI355X at 200 M records they LOSE: whole pipeline 10.73 ms against 10.15 ms with 4096-key tiles
+    // (64 KB of LDS per workgroup leaves two workgroups per CU), so the default stays 4096
+    const bool wide = c->wide_tiles > 0;
+    return wide ? radix_sort_w<8>(c, s, q, key, p64, p32, n, first_shift, bits, cur, low32_out, low32_done)
+                : radix_sort_w<kScatterWaves>(c, s, q, key, p64, p32, n, first_shift, bits, cur, low32_out, low32_done);
 }
 
 // duplicate search over one sorted entry array: run heads -> dense list -> marks (+ long runs)
@@ -1224,6 +1259,7 @@ void mgx_sortdedup_destroy(mgx_sortdedup_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_buffers(c);
+    (void)hipFree(c->d_recs); (void)hipFree(c->d_wire[0]); (void)hipFree(c->d_wire[1]);
     (void)hipFree(c->d_indicator); (void)hipFree(c->d_sub_start); (void)hipFree(c->d_sc);
     (void)hipFree(c->d_ocoord); (void)hipFree(c->d_oarr); (void)hipFree(c->d_marks);
     for (int i = 0; i < 2; ++i) { if (c->pinned[i]) (void)hipHostFree(c->pinned[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
@@ -1239,7 +1275,25 @@ void mgx_sortdedup_destroy(mgx_sortdedup_t* c) {
 
 namespace {
 
-// bitmap, sub-tile table and the per-input decisions shared by both upload forms
+// device room for `n` records; the first `keep` records already uploaded survive a growth
+int ensure_recs(mgx_sortdedup_t* c, size_t n, size_t keep) {
+    if (n <= c->recs_cap) return 0;
+    size_t cap = std::max<size_t>(n, keep ? c->recs_cap + c->recs_cap / 2 : 0);
+    mgx_rec_t* fresh = nullptr;
+    if (hipMalloc((void**)&fresh, std::max<size_t>(cap, 1) * sizeof(mgx_rec_t)) != hipSuccess) {
+        set_error("out of device memory for %zu records", cap);
+        return -ENOMEM;
+    }
+    if (keep && c->d_recs) {
+        HIP_TRY(hipMemcpyAsync(fresh, c->d_recs, keep * sizeof(mgx_rec_t), hipMemcpyDeviceToDevice, c->copy));
+        HIP_TRY(hipStreamSynchronize(c->copy));
+    }
+    (void)hipFree(c->d_recs);
+    c->d_recs = fresh; c->recs_cap = cap;
+    return 0;
+}
+
+// bitmap, sub-tile table, work buffers and the per-input decisions shared by all upload forms
 int prepare_input(mgx_sortdedup_t* c, uint64_t L, size_t capacity) {
     int rc = ensure_capacity(c, capacity);
     if (rc) { set_error("out of device memory for %zu records", capacity); return rc; }
@@ -1268,37 +1322,56 @@ int prepare_input(mgx_sortdedup_t* c, uint64_t L, size_t capacity) {
     return 0;
 }
 
+int ensure_staging(mgx_sortdedup_t* c, size_t chunk) {
+    if (chunk <= c->pinned_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    for (int i = 0; i < 2; ++i) {
+        if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+        (void)hipFree(c->d_wire[i]);
+        c->pinned[i] = nullptr; c->d_wire[i] = nullptr;
+    }
+    c->pinned_cap = 0;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipHostMalloc(&c->pinned[i], chunk, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&c->d_wire[i], chunk));
+    }
+    c->pinned_cap = chunk;
+    return 0;
+}
+
+int upload_threads() {
+    // one core copies ~12 GB/s into the staging buffer, less than a quarter of what the link takes:
+    // split every piece over a few threads (MGX_UPLOAD_THREADS, default 4)
+    static const int n_thr = [] { const char* e = getenv("MGX_UPLOAD_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    return n_thr;
+}
+
+extern "C++" {
+template <class F>
+void split_over_threads(size_t n_items, size_t min_per_thread, F body) {      // body(first, last)
+    const int n_thr = upload_threads();
+    if (n_thr == 1 || n_items < 2 * min_per_thread) { body((size_t)0, n_items); return; }
+    std::thread th[16];
+    const size_t part = (n_items + (size_t)n_thr - 1) / (size_t)n_thr;
+    int used = 0;
+    for (size_t o = 0; o < n_items; o += part) th[used++] = std::thread([=] { body(o, std::min(n_items, o + part)); });
+    for (int t = 0; t < used; ++t) th[t].join();
+}
+}  // extern "C++"
+
 // host memory -> HBM through two pinned staging buffers on the copy stream (asynchronous; the caller syncs)
 int stream_up(mgx_sortdedup_t* c, void* dst, const void* src_, size_t total) {
     if (!total) return 0;
-    const size_t chunk = std::min(kPinnedChunk, std::max<size_t>((total + 1) / 2, 1u << 20));
-    if (chunk > c->pinned_cap) {
-        HIP_TRY(hipStreamSynchronize(c->copy));
-        for (int i = 0; i < 2; ++i) { if (c->pinned[i]) (void)hipHostFree(c->pinned[i]); c->pinned[i] = nullptr; }
-        c->pinned_cap = 0;
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipHostMalloc(&c->pinned[i], chunk, hipHostMallocDefault));
-        c->pinned_cap = chunk;
-    }
+    int rc = ensure_staging(c, std::min(kPinnedChunk, std::max<size_t>((total + 1) / 2, 1u << 20)));
+    if (rc) return rc;
     size_t off = 0;
     int buf = 0;
     while (off < total) {
         const size_t len = std::min(c->pinned_cap, total - off);
         HIP_TRY(hipEventSynchronize(c->pin_ev[buf]));
-        {
-            // one core copies ~12 GB/s into the staging buffer, less than half of what the link takes:
-            // split the chunk over a few threads (MGX_UPLOAD_THREADS, default 4)
-            static const int n_thr = [] { const char* e = getenv("MGX_UPLOAD_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-            const char* src = reinterpret_cast<const char*>(src_) + off;
-            char* stage = static_cast<char*>(c->pinned[buf]);
-            if (n_thr == 1 || len < (8u << 20)) memcpy(stage, src, len);
-            else {
-                std::thread th[16];
-                const size_t part = (len / (size_t)n_thr + 4095) & ~(size_t)4095;
-                int used = 0;
-                for (size_t o = 0; o < len; o += part) th[used++] = std::thread([=] { memcpy(stage + o, src + o, std::min(part, len - o)); });
-                for (int t = 0; t < used; ++t) th[t].join();
-            }
-        }
+        const char* src = reinterpret_cast<const char*>(src_) + off;
+        char* stage = static_cast<char*>(c->pinned[buf]);
+        split_over_threads(len, 4u << 20, [=](size_t a, size_t b) { memcpy(stage + a, src + a, b - a); });
         HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, c->pinned[buf], len, hipMemcpyHostToDevice, c->copy));
         HIP_TRY(hipEventRecord(c->pin_ev[buf], c->copy));
         off += len; buf ^= 1;
@@ -1306,20 +1379,92 @@ int stream_up(mgx_sortdedup_t* c, void* dst, const void* src_, size_t total) {
     return 0;
 }
 
+// records -> d_recs[first ...): 24-byte wire form whenever the piece allows it (MGX_SORTDEDUP_WIRE=32 keeps the raw form)
+int stream_up_recs(mgx_sortdedup_t* c, uint64_t first, uint64_t n, const mgx_rec_t* recs) {
+    if (!n) return 0;
+    static const bool compact_ok = [] { const char* e = getenv("MGX_SORTDEDUP_WIRE"); return !(e && atoi(e) == 32); }();
+    const size_t total = (size_t)n * sizeof(mgx_rec_t);
+    int rc = ensure_staging(c, std::min(kPinnedChunk, std::max<size_t>((total + 1) / 2, 1u << 20)));
+    if (rc) return rc;
+    const size_t piece = c->pinned_cap / sizeof(mgx_rec_t);
+    int buf = 0;
+    for (uint64_t off = 0; off < n; off += piece, buf ^= 1) {
+        const size_t m = (size_t)std::min<uint64_t>(piece, n - off);
+        HIP_TRY(hipEventSynchronize(c->pin_ev[buf]));
+        const mgx_rec_t* src = recs + off;
+        mgx_rec_t* dst = c->d_recs + first + off;
+        bool compact = compact_ok;
+        if (compact) {
+            Wire24* w = static_cast<Wire24*>(c->pinned[buf]);
+            std::atomic<uint64_t> high{0};
+            split_over_threads(m, 65536, [&, w, src](size_t a, size_t b) {
+                uint64_t hi = 0;
+                for (size_t i = a; i < b; ++i) {
+                    const mgx_rec_t r = src[i];
+                    hi |= r.coord | r.prime5;
+                    w[i] = Wire24{(u32)r.coord, (u32)r.prime5, r.mate, r.flag, r.score, r.tile, r.x, r.y, 0};
+                }
+                if (hi >> 32) high.fetch_or(1);
+            });
+            compact = high.load() == 0;
+        }
+        if (compact) {
+            HIP_TRY(hipMemcpyAsync(c->d_wire[buf], c->pinned[buf], m * sizeof(Wire24), hipMemcpyHostToDevice, c->copy));
+            hipLaunchKernelGGL(k_expand24, dim3((u32)((m + 255) / 256)), dim3(256), 0, c->copy, (const Wire24*)c->d_wire[buf], dst, (u32)m);
+        } else {
+            char* stage = static_cast<char*>(c->pinned[buf]);
+            const char* s8 = reinterpret_cast<const char*>(src);
+            split_over_threads(m * sizeof(mgx_rec_t), 4u << 20, [=](size_t a, size_t b) { memcpy(stage + a, s8 + a, b - a); });
+            HIP_TRY(hipMemcpyAsync(dst, c->pinned[buf], m * sizeof(mgx_rec_t), hipMemcpyHostToDevice, c->copy));
+        }
+        HIP_TRY(hipEventRecord(c->pin_ev[buf], c->copy));
+    }
+    return 0;
+}
+
 }  // namespace
 
-int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, const mgx_rec_t* recs) {
+int mgx_sortdedup_upload_begin(mgx_sortdedup_t* c, uint64_t L, uint64_t n_expected) {
     if (!c) { set_error("ctx is NULL"); return -EINVAL; }
-    if (n_records >= 0xFFFFFFF0ull) { set_error("more than 2^32 records in one shard"); return -E2BIG; }
-    if (n_records && !recs) { set_error("recs is NULL"); return -EINVAL; }
+    if (n_expected >= 0xFFFFFFF0ull) { set_error("more than 2^32 records in one shard"); return -E2BIG; }
     HIP_TRY(hipSetDevice(c->device));
-    int rc = prepare_input(c, L, (size_t)n_records);
+    int rc = ensure_recs(c, (size_t)n_expected, 0);
+    if (rc) return rc;
+    c->up_L = L; c->up_high = 0; c->uploading = true; c->ran = false;
+    return 0;
+}
+
+int mgx_sortdedup_upload_chunk(mgx_sortdedup_t* c, uint64_t first_record, uint64_t n_records, const mgx_rec_t* recs) {
+    if (!c) { set_error("ctx is NULL"); return -EINVAL; }
+    if (!c->uploading) { set_error("mgx_sortdedup_upload_begin has not been called"); return -EINVAL; }
+    if (n_records && !recs) { set_error("recs is NULL"); return -EINVAL; }
+    if (first_record + n_records >= 0xFFFFFFF0ull) { set_error("more than 2^32 records in one shard"); return -E2BIG; }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_recs(c, (size_t)(first_record + n_records), (size_t)c->up_high);
+    if (rc) return rc;
+    if ((rc = stream_up_recs(c, first_record, n_records, recs))) return rc;
+    c->up_high = std::max(c->up_high, first_record + n_records);
+    return 0;
+}
+
+int mgx_sortdedup_upload_end(mgx_sortdedup_t* c, uint64_t n_records) {
+    if (!c) { set_error("ctx is NULL"); return -EINVAL; }
+    if (!c->uploading) { set_error("mgx_sortdedup_upload_begin has not been called"); return -EINVAL; }
+    if (n_records != c->up_high) { set_error("%llu records announced, chunks covered %llu", (unsigned long long)n_records, (unsigned long long)c->up_high); return -EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    c->uploading = false;
+    int rc = prepare_input(c, c->up_L, (size_t)n_records);
     if (rc) return rc;
     c->n = c->n_order = (u32)n_records; c->sharded = false; c->n_marks = 0;
-    // records are streamed through two pinned staging buffers on the copy stream
-    if ((rc = stream_up(c, c->d_recs, recs, (size_t)n_records * sizeof(mgx_rec_t)))) return rc;
     HIP_TRY(hipStreamSynchronize(c->copy));
     return 0;
+}
+
+int mgx_sortdedup_upload(mgx_sortdedup_t* c, uint64_t L, uint64_t n_records, const mgx_rec_t* recs) {
+    int rc = mgx_sortdedup_upload_begin(c, L, n_records);
+    if (!rc) rc = mgx_sortdedup_upload_chunk(c, 0, n_records, recs);
+    if (!rc) rc = mgx_sortdedup_upload_end(c, n_records);
+    return rc;
 }
 
 int mgx_sortdedup_upload_shard(mgx_sortdedup_t* c, uint64_t L, const mgx_sortdedup_shard_t* sh) {
@@ -1328,7 +1473,9 @@ int mgx_sortdedup_upload_shard(mgx_sortdedup_t* c, uint64_t L, const mgx_sortded
     if ((sh->n_order && (!sh->order_coord || !sh->order_arrival)) || (sh->n_mark && (!sh->mark_recs || !sh->mark_arrival)) ||
         (sh->n_marks && !sh->marks)) { set_error("a shard array is NULL (was the shard materialised by mgx_sortdedup_route?)"); return -EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
-    int rc = prepare_input(c, L, (size_t)std::max(sh->n_order, sh->n_mark));
+    c->uploading = false;
+    int rc = ensure_recs(c, (size_t)sh->n_mark, 0);
+    if (!rc) rc = prepare_input(c, L, (size_t)std::max(sh->n_order, sh->n_mark));
     if (rc) return rc;
     if (sh->n_order > c->order_cap) {
         (void)hipFree(c->d_ocoord); (void)hipFree(c->d_oarr); c->d_ocoord = nullptr; c->d_oarr = nullptr; c->order_cap = 0;
@@ -1341,7 +1488,7 @@ int mgx_sortdedup_upload_shard(mgx_sortdedup_t* c, uint64_t L, const mgx_sortded
         c->marks_cap = sh->n_marks;
     }
     c->n = (u32)sh->n_mark; c->n_order = (u32)sh->n_order; c->n_marks = (u32)sh->n_marks; c->sharded = true;
-    if ((rc = stream_up(c, c->d_recs, sh->mark_recs, (size_t)sh->n_mark * sizeof(mgx_rec_t)))) return rc;
+    if ((rc = stream_up_recs(c, 0, sh->n_mark, sh->mark_recs))) return rc;
     if ((rc = stream_up(c, c->d_ocoord, sh->order_coord, (size_t)sh->n_order * 8))) return rc;
     if ((rc = stream_up(c, c->d_oarr, sh->order_arrival, (size_t)sh->n_order * 4))) return rc;
     if ((rc = stream_up(c, c->d_marks, sh->marks, (size_t)sh->n_marks * 8))) return rc;
@@ -1410,6 +1557,7 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     // other sorts' bandwidth-bound scatters.  In-process A/B on one device at 200 M records
     // (tools/dev_sort_ab.py): 18.0 ms against 19.4 ms on a single stream (MGX_SORTDEDUP_STREAMS=1).
     if (const char* e = getenv("MGX_SORTDEDUP_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
+    { const char* e = getenv("MGX_SORTDEDUP_WIDE_TILES"); c->wide_tiles = e ? (atoi(e) != 0) : -1; }
     if (const char* e = getenv("MGX_SORTDEDUP_NEAR_EXACT")) { if (atoi(e) != 0) c->near_by_position = false; }
     const char* env_streams = getenv("MGX_SORTDEDUP_STREAMS");
     const bool multi = !(env_streams && atoi(env_streams) == 1);

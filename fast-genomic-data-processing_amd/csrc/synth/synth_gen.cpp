@@ -114,4 +114,63 @@ void synth_pairhmm_fill(const synth_pairhmm_params* p, uint64_t n, const uint64_
     });
 }
 
+
+// synth.gen_sortdedup_packed: BASELINE.json configs[3] as packed 32-byte records (mgx_rec_t layout) in arrival
+// order; template t fills records 2t and 2t + 1.  out must hold 2 * n_templates records.
+struct synth_rec { uint64_t coord, prime5; uint32_t mate; uint16_t flag, score, tile, x, y, pad_; };
+
+void synth_sortdedup_packed(uint64_t seed, uint64_t n_pair_t, uint64_t n_frag_t, uint64_t L, int read_len, double dup_thr,
+                            synth_rec* out, int threads) {
+    const uint64_t n_t = n_pair_t + n_frag_t;
+    struct Tpl { uint64_t start1, start2; bool r1, r2; uint64_t w2; };
+    auto base = [=](uint64_t t) {
+        Stream g{seed ^ (t * kStreamMul)};
+        const uint64_t w = g.next(), w2 = g.next();
+        Tpl r;
+        r.start1 = w % (L - 4000) + 1000;
+        r.start2 = r.start1 + 200 + (w2 & 0xFFFF) % 400;
+        const int64_t o = (int64_t)((w2 >> 16) & 0xFF);
+        r.r1 = (o >= 230) && ((o < 243) || (o >= 250));
+        r.r2 = (o < 230) || (o >= 250);
+        r.w2 = w2;
+        return r;
+    };
+    parallel_for(n_t, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t t = a; t < b; ++t) {
+            Tpl me = base(t);
+            const bool isdup = t > 0 && (double)((me.w2 >> 24) & 0xFFFF) < dup_thr;
+            if (isdup) {
+                uint64_t src = (me.w2 >> 40) % (n_t ? n_t : 1);
+                src = std::min(src, t - 1);
+                const Tpl o = base(src);            // the source's OWN draw (a copy of a copy is not followed)
+                me.start1 = o.start1; me.start2 = o.start2; me.r1 = o.r1; me.r2 = o.r2;
+            }
+            Stream g{seed ^ (t * kStreamMul)};
+            g.next(); g.next();
+            const uint64_t w3 = g.next();
+            const uint64_t clip1 = (w3 & 0xFF) < 26 ? (w3 >> 8) % 20 + 1 : 0;
+            const uint64_t clip2 = ((w3 >> 16) & 0xFF) < 26 ? (w3 >> 24) % 20 + 1 : 0;
+            const uint64_t sc1 = ((w3 >> 32) & 0xFFFF) % (uint64_t)(read_len * 30) + 1000;
+            const uint64_t sc2 = ((w3 >> 48) & 0xFFFF) % (uint64_t)(read_len * 30) + 1000;
+            const uint64_t rl = (uint64_t)(read_len - 1);
+            synth_rec A{}, B{};
+            A.prime5 = me.start1; B.prime5 = me.start2;
+            A.coord = me.r1 ? me.start1 - rl + clip1 : me.start1 + clip1;
+            B.coord = me.r2 ? me.start2 - rl + clip2 : me.start2 + clip2;
+            A.flag = (uint16_t)(1 | 2 | 64 | (me.r1 ? 16 : 0) | (me.r2 ? 32 : 0));
+            B.flag = (uint16_t)(1 | 2 | 128 | (me.r2 ? 16 : 0) | (me.r1 ? 32 : 0));
+            A.score = (uint16_t)sc1; B.score = (uint16_t)sc2;
+            A.tile = B.tile = (uint16_t)((t >> 32) & 0xFFFF); A.x = B.x = (uint16_t)((t >> 16) & 0xFFFF); A.y = B.y = (uint16_t)(t & 0xFFFF);
+            A.mate = (uint32_t)(2 * t + 1); B.mate = (uint32_t)(2 * t);
+            if (t >= n_pair_t) {                    // fragment: record A mapped and single, B its unmapped mate at the same coordinate
+                A.mate = B.mate = 0xFFFFFFFFu;
+                A.flag = (uint16_t)((1 | 8 | 64) | (me.r1 ? 16 : 0));
+                B.flag = (uint16_t)(1 | 4 | 128);
+                B.coord = A.coord; B.prime5 = A.coord;
+            }
+            out[2 * t] = A; out[2 * t + 1] = B;
+        }
+    });
+}
+
 }  // extern "C"

@@ -70,6 +70,7 @@ PAIRHMM_SYMBOLS = {
     "mgx_pairhmm_queue_destroy": (None, [C.c_void_p]),
     "mgx_pairhmm_queue_run": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_queue_run_range": (C.c_int, [C.c_void_p, C.POINTER(PairHMMInput), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mgx_pairhmm_queue_run_regions": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mgx_pairhmm_queue_stats": (C.c_int, [C.c_void_p, C.POINTER(QueueStats)]),
     "mgx_pairhmm_pack_batch": (C.c_int, [C.POINTER(PairHMMInput), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t,
                                          C.POINTER(PairHMMInput), C.POINTER(C.c_size_t)]),
@@ -146,6 +147,9 @@ SORTDEDUP_SYMBOLS = {
     "mgx_sortdedup_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
     "mgx_sortdedup_destroy": (None, [C.c_void_p]),
     "mgx_sortdedup_upload": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "mgx_sortdedup_upload_begin": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "mgx_sortdedup_upload_chunk": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "mgx_sortdedup_upload_end": (C.c_int, [C.c_void_p, C.c_uint64]),
     "mgx_sortdedup_run": (C.c_int, [C.c_void_p]),
     "mgx_sortdedup_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_sortdedup_stats": (C.c_int, [C.c_void_p, C.POINTER(SortDedupStats)]),

@@ -44,6 +44,22 @@ def make_input(d):
     return inp, keep
 
 
+def prepare_regions(regions):
+    """ctypes marshalling of a list of regions (dicts in the cross-product form) for compute_regions /
+    run_regions, done once so that a timed call measures the library and not the Python veneer."""
+    n = len(regions)
+    arr = (native.PairHMMInput * n)()
+    keeps, outs = [], []
+    ptrs = (C.c_void_p * n)()
+    for g, d in enumerate(regions):
+        d = dict(d); d["pair_read"] = None; d["pair_hap"] = None
+        inp, keep = make_input(d)
+        arr[g] = inp; keeps.append(keep)
+        o = np.empty((int(inp.n_reads), int(inp.n_haps)), dtype=np.float64)
+        outs.append(o); ptrs[g] = o.ctypes.data
+    return dict(n=n, arr=arr, keeps=keeps, outs=outs, ptrs=ptrs)
+
+
 def pack_batch(d, lo, hi):
     """The work queue's host packer (no device): test cases [lo, hi) of the stream ``d`` as a
     self-contained dict in the same packed layout -- every referenced read / haplotype once, in
@@ -94,6 +110,12 @@ class PairHMMQueue:
         used = np.zeros(hi - lo, dtype=np.uint8) if with_flags else None
         native.check(self.lib.mgx_pairhmm_queue_run_range(self.q, C.byref(inp), lo, hi, _ptr(out), _ptr(used) if with_flags else None))
         return (out, used) if with_flags else out
+
+    def run_regions(self, regions=None, prepared=None):
+        """Row F1 through the queue: one [n_reads][n_haps] array per region."""
+        p = prepared if prepared is not None else prepare_regions(regions)
+        native.check(self.lib.mgx_pairhmm_queue_run_regions(self.q, p["n"], C.cast(p["arr"], C.c_void_p), C.cast(p["ptrs"], C.c_void_p)))
+        return p["outs"]
 
     def stats(self):
         st = native.QueueStats()
@@ -166,21 +188,12 @@ class PairHMMEngine:
         native.check(self.lib.mgx_pairhmm_compute(self.ctx, C.byref(inp), _ptr(out)))
         return out
 
-    def compute_regions(self, regions):
+    def compute_regions(self, regions=None, prepared=None):
         """Row F1: several active regions (dicts in the cross-product form) in ONE device batch.
         Returns one [n_reads][n_haps] array per region."""
-        n = len(regions)
-        arr = (native.PairHMMInput * n)()
-        keeps, outs = [], []
-        ptrs = (C.c_void_p * n)()
-        for g, d in enumerate(regions):
-            d = dict(d); d["pair_read"] = None; d["pair_hap"] = None
-            inp, keep = make_input(d)
-            arr[g] = inp; keeps.append(keep)
-            o = np.empty((int(inp.n_reads), int(inp.n_haps)), dtype=np.float64)
-            outs.append(o); ptrs[g] = o.ctypes.data
-        native.check(self.lib.mgx_pairhmm_compute_regions(self.ctx, n, C.cast(arr, C.c_void_p), C.cast(ptrs, C.c_void_p)))
-        return outs
+        p = prepared if prepared is not None else prepare_regions(regions)
+        native.check(self.lib.mgx_pairhmm_compute_regions(self.ctx, p["n"], C.cast(p["arr"], C.c_void_p), C.cast(p["ptrs"], C.c_void_p)))
+        return p["outs"]
 
     def regions(self, regions, mapqs, **model_overrides):
         """Rows F1 + F2: computeReadLikelihoods for several regions in one device batch.

@@ -95,6 +95,18 @@ class SortDedupEngine:
         self.n = self.n_order = len(recs)
         native.check(self.lib.mgx_sortdedup_upload(self.ctx, L, self.n, _ptr(recs)))
 
+    def upload_chunks(self, L, chunks, n_expected=0):
+        """Streamed upload: ``chunks`` yields record arrays in arrival order (mate indices global)."""
+        native.check(self.lib.mgx_sortdedup_upload_begin(self.ctx, L, n_expected))
+        at = 0
+        for ch in chunks:
+            ch = np.ascontiguousarray(ch)
+            assert ch.dtype == REC_DTYPE
+            native.check(self.lib.mgx_sortdedup_upload_chunk(self.ctx, at, len(ch), _ptr(ch)))
+            at += len(ch)
+        native.check(self.lib.mgx_sortdedup_upload_end(self.ctx, at))
+        self.n = self.n_order = at
+
     def upload_shard(self, routed, k):
         """One shard of a routed record set: results() then returns (global arrival indices of the shard's
         records in output order, duplicate flag per marking record)."""

@@ -411,6 +411,23 @@ def gen_sortdedup_packed(n_records, seed, n_contigs=25, contig_len=124_000_000, 
     return rec[:n_records] if 2 * n_t >= n_records else rec, L
 
 
+def gen_sortdedup_packed_fast(n_records, seed, n_contigs=25, contig_len=124_000_000, read_len=150, dup_rate=0.10,
+                              frag_frac=0.03, threads=0):
+    """gen_sortdedup_packed, byte for byte, by the threaded C++ generator (200 M records in seconds)."""
+    import ctypes as C
+    import os
+    lib = _synth_lib()
+    threads = threads or min(len(os.sched_getaffinity(0)), 32)
+    L = n_contigs * contig_len
+    n_frag_t = int(n_records * frag_frac / 2)
+    n_pair_t = (n_records - 2 * n_frag_t) // 2
+    n_t = n_pair_t + n_frag_t
+    rec = np.empty(2 * n_t, dtype=REC_DTYPE)
+    lib.synth_sortdedup_packed(C.c_uint64(seed), C.c_uint64(n_pair_t), C.c_uint64(n_frag_t), C.c_uint64(L), C.c_int(read_len),
+                               C.c_double(dup_rate * 65536), rec.ctypes.data_as(C.c_void_p), C.c_int(threads))
+    return (rec[:n_records] if 2 * n_t >= n_records else rec), L
+
+
 def gen_sw_pairs(n_pairs, seed, ref_range=(40, 400), alt_range=(20, 250), strategies=(9, 10, 11, 12)):
     """Smith-Waterman workload: reference windows and alternates that are mutated sub-ranges of them
     (substitutions, insertions, deletions, random flanks), plus a share of unrelated sequences.

@@ -191,6 +191,12 @@ int mgx_pairhmm_queue_run(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_t* in,
  * split over several (one process per GPU): out_log10[i - pair_begin]. */
 int mgx_pairhmm_queue_run_range(mgx_pairhmm_queue_t* q, const mgx_pairhmm_input_t* in, uint64_t pair_begin, uint64_t pair_end,
                                 double* out_log10, uint8_t* used_f64);
+/* Row F1 through the queue: many active regions in the cross-product form (what HipLoglessPairHMM::enqueue parks);
+ * lanes pull runs of whole regions holding about batch_pairs test cases, so that flattening and uploading the next
+ * regions overlaps the kernels of the previous ones.  out_log10[g] receives region g's [n_reads][n_haps] block;
+ * values are identical to mgx_pairhmm_compute_regions / one mgx_pairhmm_compute per region. */
+int mgx_pairhmm_queue_run_regions(mgx_pairhmm_queue_t* q, uint32_t n_regions, const mgx_pairhmm_input_t* regions,
+                                  double* const* out_log10);
 int mgx_pairhmm_queue_stats(mgx_pairhmm_queue_t* q, mgx_pairhmm_queue_stats_t* out);
 /* Host only (no device): the queue's packer.  Test cases [pair_begin, pair_end) of `in` as a self-contained
  * batch laid out in buf: *out points into buf, local indices, every referenced read / haplotype once, in

@@ -97,6 +97,16 @@ void mgx_sortdedup_destroy(mgx_sortdedup_t* ctx);
  *   out_dup[i]   = 1 iff arrival record i gets BAM_FDUP (0x400) set (a pre-existing 0x400 is
  *                  never cleared, main.cpp:385-388 only ever sets it). */
 int mgx_sortdedup_upload(mgx_sortdedup_t* ctx, uint64_t L, uint64_t n_records, const mgx_rec_t* recs);
+/* The same upload in pieces, for a producer that packs records while it is still parsing (the reference's reader
+ * feeds its shuffle threads through a bounded queue of line blocks, sortmardup/main.cpp:505-562; here the pieces go
+ * straight to the device, so parsing, staging and the PCIe copy overlap):
+ *   begin   n_expected is a capacity hint (0 is fine; the device array grows when a chunk exceeds it)
+ *   chunk   records [first_record, first_record + n_records) in arrival order; mate indices are GLOBAL arrival
+ *           indices; returns once the caller's buffer may be reused (the device copy continues in the background)
+ *   end     n_records must equal the extent the chunks covered; waits for the copies */
+int mgx_sortdedup_upload_begin(mgx_sortdedup_t* ctx, uint64_t L, uint64_t n_expected);
+int mgx_sortdedup_upload_chunk(mgx_sortdedup_t* ctx, uint64_t first_record, uint64_t n_records, const mgx_rec_t* recs);
+int mgx_sortdedup_upload_end(mgx_sortdedup_t* ctx, uint64_t n_records);
 int mgx_sortdedup_run(mgx_sortdedup_t* ctx);
 int mgx_sortdedup_results(mgx_sortdedup_t* ctx, uint32_t* out_order, uint8_t* out_dup);
 int mgx_sortdedup_stats(mgx_sortdedup_t* ctx, mgx_sortdedup_stats_t* out);

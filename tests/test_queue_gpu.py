@@ -87,3 +87,21 @@ def test_pair_count_without_pair_arrays_is_rejected(pkg, synth):
     rc = eng.lib.mgx_pairhmm_compute(eng.ctx, C.byref(inp), out.ctypes.data_as(C.c_void_p))
     assert rc == -22
     eng.close()
+
+
+def test_regions_through_the_queue(pkg, engine, synth):
+    """Row F1 through the queue: runs of whole regions pulled by the lanes; values identical to one call per region."""
+    regions = [synth.gen_pairhmm_region(5 + (g * 7) % 40, 1 + (g * 3) % 25, 100 + g, r_range=(20, 128), h_range=(64, 256)) for g in range(60)]
+    want = [engine.compute(dict(r, pair_read=None, pair_hap=None)).reshape(len(r["read_off"]) - 1, len(r["hap_off"]) - 1) for r in regions]
+    q = pkg.PairHMMQueue(devices=(0,), lanes_per_device=3, depth=2, batch_pairs=3000)
+    got = q.run_regions(regions)
+    st = q.stats()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert st["n_batches"] > 3 and st["n_pairs"] == sum(w.size for w in want)
+    one = engine.compute_regions(regions)
+    assert all(np.array_equal(a, b) for a, b in zip(one, want))
+    # a region larger than batch_pairs is a batch of its own; empty lists are fine
+    big = [synth.gen_pairhmm_region(90, 40, 7, r_range=(20, 60), h_range=(40, 90))]
+    assert np.array_equal(q.run_regions(big)[0], engine.compute_regions(big)[0])
+    assert q.run_regions([]) == []
+    q.close()

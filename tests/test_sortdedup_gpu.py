@@ -213,3 +213,28 @@ def test_out_of_range_mate_is_an_error_not_a_fault(pkg, sd_engine, synth):
     recs["mate"][77] = 5_000_000
     with pytest.raises(pkg.MgxError, match="mate index"):
         sd_engine.sort_mark(L, recs)
+
+
+def test_streamed_upload_equals_one_shot(pkg, sd_engine, synth, monkeypatch):
+    """mgx_sortdedup_upload_begin / _chunk / _end (pieces of any size, capacity hint too small so the device array
+    grows) must leave the same records in HBM as the one-shot upload; so must the raw 32-byte wire form."""
+    recs, L = synth.gen_sortdedup_packed(3_000_001, 17)
+    want = sd_engine.sort_mark(L, recs)
+    cuts = [0, 1, 70_000, 70_001, 1_500_000, 2_999_999, len(recs)]
+    sd_engine.upload_chunks(L, (recs[a:b] for a, b in zip(cuts, cuts[1:])), n_expected=1000)
+    sd_engine.run()
+    got = sd_engine.results()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # a piece with a 5' end that wrapped below zero does not fit the 24-byte wire form: that piece travels raw
+    wrapped = recs.copy()
+    wrapped["prime5"][123_456] = np.uint64(2**64 - 5)
+    a = sd_engine.sort_mark(L, wrapped)
+    eng2 = pkg.SortDedupEngine(0)
+    eng2.upload_chunks(L, [wrapped[:100_000], wrapped[100_000:]])
+    eng2.run()
+    b = eng2.results()
+    eng2.close()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    with pytest.raises(pkg.MgxError):
+        sd_engine.lib.mgx_sortdedup_upload_begin(sd_engine.ctx, L, 10)
+        pkg.native.check(sd_engine.lib.mgx_sortdedup_upload_end(sd_engine.ctx, 5))
