@@ -271,6 +271,87 @@ def pairhmm_rooflines(st, traffic):
              "kernel_gcups": st["dominant_cells"] / (ms_dom * 1e-3) / 1e9, "note": "12 flop per cell (SURVEY.md 8d) against the fp32 vector peak"})
 
 
+def regions_leg(pkg, synth, local_rank, lanes):
+    """Row F1: 1000 active regions of 40 reads x 25 haplotypes, host buffers in -> results in host
+    memory out, timed around the C call only (the ctypes marshalling is done beforehand): one device batch
+    (mgx_pairhmm_compute_regions) and the same through the queue (lanes flatten / upload the next regions while the
+    previous ones compute)."""
+    distinct = [synth.gen_pairhmm_region(40, 25, 1000 + g, r_range=(20, 128), h_range=(64, 256)) for g in range(50)]
+    regions = [distinct[g % len(distinct)] for g in range(1000)]
+    cells = sum(r["cells"] for r in regions)
+    prep = pkg.pairhmm.prepare_regions(regions)
+    eng = pkg.PairHMMEngine(local_rank)
+    eng.compute_regions(prepared=prep)
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter(); eng.compute_regions(prepared=prep); ts.append(time.perf_counter() - t0)
+    one = float(np.median(ts))
+    want = [x.copy() for x in prep["outs"]]
+    q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
+    q.run_regions(prepared=prep)
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter(); got = q.run_regions(prepared=prep); ts.append(time.perf_counter() - t0)
+    qt = float(np.median(ts))
+    same = all(np.array_equal(a, b) for a, b in zip(got, want))
+    q.close(); eng.close()
+    return {"metric": "PairHMM GCUPS, 1000 regions of 40 reads x 25 haplotypes (row F1), host buffers in -> host results out",
+            "cells": cells, "one_batch": {"ms": one * 1e3, "value": cells / one / 1e9, "unit": "GCUPS"},
+            "queue": {"ms": qt * 1e3, "value": cells / qt / 1e9, "unit": "GCUPS", "lanes": lanes, "identical_to_one_batch": same},
+            "note": "read U[20,128] x haplotype U[64,256]; includes flattening, H2D, kernels, D2H and the scatter into per-region outputs"}
+
+
+def mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_over_ranks):
+    """BASELINE.json configs[4]: the PairHMM work queue and the sort / mark-duplicate pipeline co-resident on every GPU,
+    each driven by its own host thread on its own streams; measured alone and together over the same wall-clock window."""
+    import threading
+    total = args.total_pairs if world > 1 else 4 << 20
+    lo, hi = shard.shard_bounds(total, rank, world)
+    n_local = min(hi - lo, 4 << 20)                    # a window of the rank's shard keeps the leg short
+    d = synth.gen_pairhmm_pairs_fast(n_local, 0x5EED0003, first_pair=lo)
+    prepared = pkg.pairhmm.make_input(d)
+    lanes = args.queue_lanes or max(2, min(8, host_cores() // world))
+    q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
+    recs, L = synth.gen_sortdedup_packed_fast(max(args.sort_records // world, 1_000_000), 0x5EED0004 + rank)
+    eng = pkg.SortDedupEngine(local_rank)
+    eng.upload(L, recs)
+    q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared); eng.run(); eng.stats()
+
+    def run_for(seconds, do_hmm, do_sort):
+        stop = time.perf_counter() + seconds
+        counts = [0, 0]
+
+        def hmm():
+            while time.perf_counter() < stop:
+                q.run(d, prepared=prepared); counts[0] += 1
+
+        def srt():
+            while time.perf_counter() < stop:
+                eng.run(); eng.stats(); counts[1] += 1
+        th = [threading.Thread(target=f) for f, on in ((hmm, do_hmm), (srt, do_sort)) if on]
+        barrier()
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        return counts[0] * d["cells"] / dt / 1e9, counts[1] * len(recs) / dt / 1e6
+    hmm_alone, _ = run_for(1.5, True, False)
+    _, sort_alone = run_for(1.5, False, True)
+    hmm_mixed, sort_mixed = run_for(3.0, True, True)
+    q.close(); eng.close()
+    if rank != 0:
+        return None
+    return {"metric": "BASELINE.json configs[4]: PairHMM queue + sort/mark-duplicate pipeline co-resident, per GPU (rank 0's figures)",
+            "pairhmm_queue_gcups": {"alone": hmm_alone, "mixed": hmm_mixed}, "sortmardup_mrecords_s": {"alone": sort_alone, "mixed": sort_mixed},
+            "combined_utilisation": hmm_mixed / max(hmm_alone, 1e-9) + sort_mixed / max(sort_alone, 1e-9),
+            "config": {"pairs_per_gpu_window": n_local, "records_per_gpu": len(recs), "queue_lanes": lanes},
+            "note": "two host threads per GPU, separate contexts and streams; PairHMM streamed from host memory through the work queue, "
+                    "sort records resident (independent per-GPU record sets in this leg)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,6 +367,7 @@ def main():
     ap.add_argument("--sw-pairs", type=int, default=20000, help="Smith-Waterman pairs (row F4 leg; 0 skips it)")
     ap.add_argument("--queue-lanes", type=int, default=0, help="host lanes of the work queue (default: min(8, cores / ranks))")
     ap.add_argument("--no-ragged", action="store_true", help="skip sub-run 2b (ragged lengths)")
+    ap.add_argument("--no-regions", action="store_true", help="skip the row-F1 leg (1000 regions of 40 x 25)")
     ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[4]: PairHMM queue and sort/mark-duplicate pipeline co-resident")
     args = ap.parse_args()
 
@@ -410,7 +492,12 @@ def main():
     if args.sort_records > 0:
         sort_line = sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend)
     sw_line = smithwaterman_leg(pkg, synth, args, rank, local_rank) if args.sw_pairs > 0 else None
+    mixed_line = mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_over_ranks) if args.mixed else None
     if rank == 0:
+        if not args.no_regions:
+            line["regions"] = regions_leg(pkg, synth, local_rank, max(2, min(4, host_cores() // world)))
+        if mixed_line is not None:
+            line["mixed"] = mixed_line
         if sort_line is not None:
             line["sortmardup"] = sort_line
         if sw_line is not None:

@@ -4,16 +4,34 @@
 //     sortmardup [-I input.sam] [-t threads] -O output.bam
 // text SAM from a file or stdin; output.bam is replaced if it exists; output.bam.bai is written
 // next to it; stage timings go to stdout (time_stamp(), main.cpp:597-607).
-// Stages: read + parse (threads) -> mgx_sortdedup_pack (host keys, arrival order) ->
-// mgx_sortdedup_sort_mark (MI355X: radix sorts + duplicate search) -> BGZF/BAM/BAI (threads).
+//
+// Ingest is a pipeline over bounded slices of the text, the shape of the reference's reader thread feeding its
+// shuffle threads through a bounded queue of line blocks (main.cpp:505-562, 129-192):
+//   reader (main thread)   reads ~32 MB at a time, cuts at a template boundary (a queryname group never
+//                          straddles two slices, so mates are found inside their slice), queues the slice;
+//                          the queue is bounded, so at most 2 x threads slices of text are alive
+//   parsers (-t threads)   parse a slice into BAM-ready records and run mgx_sortdedup_pack on it (host keys,
+//                          arrival order, slice-local mate indices)
+//   commit (in slice order, by whichever parser finishes the next slice)
+//                          turns mate indices into global arrival indices and hands the packed records to
+//                          mgx_sortdedup_upload_chunk: staging and the PCIe copy run while later slices are
+//                          still being parsed; only the BAM bytes and 24 bytes of bookkeeping per record stay
+// then mgx_sortdedup_run (MI355X: radix sorts + duplicate search) and BGZF/BAM/BAI output (threads).
 // There is no CPU fallback: without a HIP device the tool exits with an error.
 #include <getopt.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -35,47 +53,76 @@ void time_stamp(const char* hint) {
     g_last = now;
 }
 
-bool read_all(const char* path, std::string* out) {
-    FILE* f = path ? fopen(path, "rb") : stdin;
-    if (!f) return false;
-    char buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
-    if (path) fclose(f);
-    return true;
-}
+struct Slice { uint64_t seq = 0; std::string text; };
 
-struct Parsed {                      // what one parser thread produces for its slice of lines
-    std::vector<uint16_t> flag; std::vector<int32_t> tid; std::vector<int64_t> pos;
-    std::vector<uint32_t> cigar; std::vector<uint64_t> cigar_len;
-    std::vector<uint8_t> qual; std::vector<uint64_t> qual_len;
-    std::vector<char> qname; std::vector<uint64_t> qname_len;
-    std::vector<uint8_t> blob; std::vector<uint64_t> blob_off;      // BAM bytes per record
-    std::vector<int32_t> end;
+struct Chunk {                       // one parsed + packed slice
+    std::vector<uint16_t> flag; std::vector<int32_t> tid; std::vector<int64_t> pos; std::vector<int32_t> end;
+    std::vector<uint32_t> cigar; std::vector<uint64_t> cigar_off{0};
+    std::vector<uint8_t> qual; std::vector<uint64_t> qual_off{0};
+    std::vector<char> qname; std::vector<uint64_t> qname_off{0};
+    std::vector<uint8_t> blob; std::vector<uint64_t> blob_off{0};      // BAM bytes per record (kept until the output is written)
+    std::vector<mgx_rec_t> recs; std::vector<uint32_t> input_index;   // arrival order inside the slice
     std::string err;
 };
 
-void parse_slice(const char* data, size_t lo, size_t hi, const samtext::Header& h, Parsed* p) {
+// what the writer needs per record, in ARRIVAL order
+struct Kept { const uint8_t* blob; uint32_t len; int32_t tid, beg, end; bool mapped; };
+
+const char* line_qname_end(const char* line, const char* end) {
+    const char* t = (const char*)memchr(line, '\t', (size_t)(end - line));
+    return t ? t : end;
+}
+
+// Offset at which the LAST queryname group of [data, data + size) starts (size ends on a line boundary).
+size_t last_group_start(const char* data, size_t size) {
+    if (size == 0) return 0;
+    size_t line_end = size;                                  // one past the '\n' of the line under inspection
+    auto line_begin = [&](size_t e) { size_t b = e - 1; while (b > 0 && data[b - 1] != '\n') --b; return b; };
+    size_t b = line_begin(line_end);
+    const char* qn = data + b; const size_t qn_len = (size_t)(line_qname_end(qn, data + line_end) - qn);
+    size_t group = b;
+    while (group > 0) {
+        const size_t pb = line_begin(group);
+        const char* pq = data + pb; const size_t pl = (size_t)(line_qname_end(pq, data + group) - pq);
+        if (pl != qn_len || memcmp(pq, qn, qn_len) != 0) break;
+        group = pb;
+    }
+    return group;
+}
+
+void parse_slice(const std::string& text, const samtext::Header& h, uint64_t L_expected, Chunk* c) {
     samtext::Record r;
-    size_t off = lo;
+    const char* data = text.data();
+    size_t off = 0, hi = text.size();
     while (off < hi) {
         const char* nl = (const char*)memchr(data + off, '\n', hi - off);
         size_t len = nl ? (size_t)(nl - (data + off)) : hi - off;
         const size_t next = off + len + 1;
         if (len && data[off + len - 1] == '\r') --len;
         if (len) {
-            if (!samtext::parse_record(data + off, len, h, &r, &p->err)) { p->err += " at: " + std::string(data + off, std::min<size_t>(len, 80)); return; }
-            p->flag.push_back(r.flag); p->tid.push_back(r.tid); p->pos.push_back(r.pos);
-            p->cigar.insert(p->cigar.end(), r.cigar.begin(), r.cigar.end()); p->cigar_len.push_back(r.cigar.size());
-            p->qual.insert(p->qual.end(), r.qual.begin(), r.qual.end()); p->qual_len.push_back(r.qual.size());
-            p->qname.insert(p->qname.end(), r.qname.begin(), r.qname.end()); p->qname_len.push_back(r.qname.size());
-            p->blob_off.push_back(p->blob.size());
-            bamout::encode_record(r, &p->blob);
-            p->end.push_back(r.end());
+            if (!samtext::parse_record(data + off, len, h, &r, &c->err)) { c->err += " at: " + std::string(data + off, std::min<size_t>(len, 80)); return; }
+            c->flag.push_back(r.flag); c->tid.push_back(r.tid); c->pos.push_back(r.pos); c->end.push_back(r.end());
+            c->cigar.insert(c->cigar.end(), r.cigar.begin(), r.cigar.end()); c->cigar_off.push_back(c->cigar.size());
+            c->qual.insert(c->qual.end(), r.qual.begin(), r.qual.end()); c->qual_off.push_back(c->qual.size());
+            c->qname.insert(c->qname.end(), r.qname.begin(), r.qname.end()); c->qname_off.push_back(c->qname.size());
+            bamout::encode_record(r, &c->blob);
+            c->blob_off.push_back(c->blob.size());
         }
         off = next;
     }
-    p->blob_off.push_back(p->blob.size());
+    const size_t n = c->flag.size();
+    mgx_raw_records_t raw{};
+    raw.n_records = n; raw.flag = c->flag.data(); raw.tid = c->tid.data(); raw.pos = c->pos.data();
+    raw.cigar_off = c->cigar_off.data(); raw.cigar = c->cigar.data(); raw.qual_off = c->qual_off.data(); raw.qual = c->qual.data();
+    raw.qname_off = c->qname_off.data(); raw.qname = c->qname.data();
+    raw.n_targets = (uint32_t)h.ref_len.size(); raw.target_len = h.ref_len.data();
+    c->recs.resize(n); c->input_index.resize(n);
+    uint64_t L = 0;
+    if (mgx_sortdedup_pack(&raw, c->recs.data(), c->input_index.data(), &L)) { c->err = std::string("pack: ") + mgx_last_error(); return; }
+    (void)L_expected;
+    // the parse-time arrays are not needed any more (the keys are in recs); keep what the writer needs
+    std::vector<uint32_t>().swap(c->cigar); std::vector<uint8_t>().swap(c->qual); std::vector<char>().swap(c->qname);
+    std::vector<uint64_t>().swap(c->cigar_off); std::vector<uint64_t>().swap(c->qual_off); std::vector<uint64_t>().swap(c->qname_off);
 }
 
 }  // namespace
@@ -85,81 +132,171 @@ int main(int argc, char** argv) {
     const char* in_path = nullptr; const char* out_path = nullptr;
     int threads = (int)std::thread::hardware_concurrency();
     int device = 0, level = 6;
+    size_t slice_bytes = 32u << 20;
     int c;
-    while ((c = getopt(argc, argv, "I:O:t:d:l:")) >= 0) {
+    while ((c = getopt(argc, argv, "I:O:t:d:l:s:")) >= 0) {
         switch (c) {
             case 'I': in_path = optarg; break;
             case 'O': out_path = optarg; break;
             case 't': threads = atoi(optarg); break;
             case 'd': device = atoi(optarg); break;          // extension: HIP device ordinal
             case 'l': level = atoi(optarg); break;           // extension: deflate level
+            case 's': slice_bytes = (size_t)atoll(optarg); break;   // extension: bytes of SAM text per slice
             default: fprintf(stderr, "usage: %s [-I input.sam] [-t num] -O output.bam\n", argv[0]); return 2;
         }
     }
     if (!out_path) { fprintf(stderr, "usage: %s [-I input.sam] [-t num] -O output.bam\n", argv[0]); return 2; }
     if (threads < 1) threads = 1;
+    if (slice_bytes < 1024) slice_bytes = 1024;
     g_t0 = g_last = clk::now();
     time_stamp("program start");
     unlink(out_path);                                        // main.cpp:66-68
 
-    std::string text;
-    if (!read_all(in_path, &text)) { fprintf(stderr, "cannot read %s\n", in_path ? in_path : "stdin"); return 1; }
-    samtext::Header hdr;
-    const size_t body = samtext::parse_header(text.data(), text.size(), &hdr);
-    // ---- parse: slices cut at line boundaries, one parser per thread
-    const int T = threads;
-    std::vector<size_t> cut(T + 1, text.size());
-    cut[0] = body;
-    for (int t = 1; t < T; ++t) {
-        size_t p = body + (text.size() - body) * (size_t)t / (size_t)T;
-        const char* nl = (const char*)memchr(text.data() + p, '\n', text.size() - p);
-        cut[t] = nl ? (size_t)(nl - text.data()) + 1 : text.size();
-        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-    }
-    std::vector<Parsed> parts(T);
-    {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < T; ++t) pool.emplace_back(parse_slice, text.data(), cut[t], cut[t + 1], std::cref(hdr), &parts[t]);
-        for (auto& th : pool) th.join();
-    }
-    for (auto& p : parts) if (!p.err.empty()) { fprintf(stderr, "SAM parse error: %s\n", p.err.c_str()); return 1; }
-    std::string().swap(text);
-    // ---- gather the structure-of-arrays view mgx_sortdedup_pack takes
-    size_t n = 0, n_cig = 0, n_q = 0, n_qn = 0;
-    for (auto& p : parts) { n += p.flag.size(); n_cig += p.cigar.size(); n_q += p.qual.size(); n_qn += p.qname.size(); }
-    std::vector<uint16_t> flag; std::vector<int32_t> tid; std::vector<int64_t> pos; std::vector<int32_t> endv;
-    std::vector<uint32_t> cigar; std::vector<uint8_t> qual; std::vector<char> qname;
-    std::vector<uint64_t> cigar_off(1, 0), qual_off(1, 0), qname_off(1, 0);
-    std::vector<const uint8_t*> blob(n); std::vector<uint32_t> blob_len(n);
-    flag.reserve(n); tid.reserve(n); pos.reserve(n); endv.reserve(n); cigar.reserve(n_cig); qual.reserve(n_q); qname.reserve(n_qn);
-    size_t k = 0;
-    for (auto& p : parts) {
-        flag.insert(flag.end(), p.flag.begin(), p.flag.end()); tid.insert(tid.end(), p.tid.begin(), p.tid.end());
-        pos.insert(pos.end(), p.pos.begin(), p.pos.end()); endv.insert(endv.end(), p.end.begin(), p.end.end());
-        cigar.insert(cigar.end(), p.cigar.begin(), p.cigar.end()); qual.insert(qual.end(), p.qual.begin(), p.qual.end());
-        qname.insert(qname.end(), p.qname.begin(), p.qname.end());
-        for (size_t i = 0; i < p.flag.size(); ++i, ++k) {
-            cigar_off.push_back(cigar_off.back() + p.cigar_len[i]); qual_off.push_back(qual_off.back() + p.qual_len[i]);
-            qname_off.push_back(qname_off.back() + p.qname_len[i]);
-            blob[k] = p.blob.data() + p.blob_off[i]; blob_len[k] = (uint32_t)(p.blob_off[i + 1] - p.blob_off[i]);
-        }
-    }
-    printf("%zu alignment records, %zu reference sequences\n", n, hdr.ref_name.size());
-    time_stamp("read + parse done");
+    FILE* f = in_path ? fopen(in_path, "rb") : stdin;
+    if (!f) { fprintf(stderr, "cannot read %s\n", in_path ? in_path : "stdin"); return 1; }
+    uint64_t file_bytes = 0;
+    { struct stat sb; if (in_path && stat(in_path, &sb) == 0) file_bytes = (uint64_t)sb.st_size; }
 
-    // ---- keys on the host, sort + duplicate search on the GPU
-    mgx_raw_records_t raw{};
-    raw.n_records = n; raw.flag = flag.data(); raw.tid = tid.data(); raw.pos = pos.data();
-    raw.cigar_off = cigar_off.data(); raw.cigar = cigar.data(); raw.qual_off = qual_off.data(); raw.qual = qual.data();
-    raw.qname_off = qname_off.data(); raw.qname = qname.data();
-    raw.n_targets = (uint32_t)hdr.ref_len.size(); raw.target_len = hdr.ref_len.data();
-    std::vector<mgx_rec_t> recs(n); std::vector<uint32_t> input_index(n); uint64_t L = 0;
-    if (mgx_sortdedup_pack(&raw, recs.data(), input_index.data(), &L)) { fprintf(stderr, "pack: %s\n", mgx_last_error()); return 1; }
-    time_stamp("pair + key derivation done");
+    // ---- header: read until a line that does not start with '@' is complete
+    std::string carry;                                       // text read but not yet handed to a parser
+    samtext::Header hdr;
+    bool eof = false;
+    std::vector<char> buf(1u << 20);
+    auto read_more = [&](size_t want) {
+        size_t got_total = 0;
+        while (!eof && got_total < want) {
+            const size_t got = fread(buf.data(), 1, std::min(buf.size(), want - got_total), f);
+            if (got == 0) { eof = true; break; }
+            carry.append(buf.data(), got); got_total += got;
+        }
+    };
+    for (;;) {
+        // the header is complete once the buffer holds a full line that does not start with '@'
+        size_t off = 0; bool body_seen = false;
+        while (off < carry.size()) {
+            if (carry[off] != '@') { body_seen = true; break; }
+            const size_t nl = carry.find('\n', off);
+            if (nl == std::string::npos) break;
+            off = nl + 1;
+        }
+        if (body_seen || eof) break;
+        read_more(1u << 20);
+    }
+    {
+        const size_t body = samtext::parse_header(carry.data(), carry.size(), &hdr);
+        carry.erase(0, body);
+    }
+    uint64_t L = 0;
+    for (uint64_t x : hdr.ref_len) L += x;
+
     mgx_sortdedup_t* sd = nullptr;
     if (mgx_sortdedup_create(device, 0, &sd)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
+    if (mgx_sortdedup_upload_begin(sd, L, file_bytes / 256)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
+
+    // ---- the pipeline
+    std::mutex mu;
+    std::condition_variable cv_work, cv_room;
+    std::deque<Slice> queue;
+    const size_t queue_cap = (size_t)threads * 2;
+    bool done_reading = false;
+    std::atomic<bool> failed{false};
+    std::string first_error;
+    // commit state (guarded by commit_mu)
+    std::mutex commit_mu;
+    std::map<uint64_t, std::unique_ptr<Chunk>> ready;
+    uint64_t next_commit = 0, n_total = 0;
+    std::vector<std::unique_ptr<Chunk>> kept_chunks;         // own the BAM bytes
+    std::vector<Kept> by_arrival;
+    if (file_bytes) by_arrival.reserve((size_t)(file_bytes / 256));
+    auto fail = [&](const std::string& msg) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!failed.exchange(true)) first_error = msg;
+        cv_work.notify_all(); cv_room.notify_all();
+    };
+    auto commit_ready = [&]() {                              // called with commit_mu held
+        for (;;) {
+            auto it = ready.find(next_commit);
+            if (it == ready.end()) return;
+            std::unique_ptr<Chunk> ch = std::move(it->second);
+            ready.erase(it);
+            const uint64_t base = n_total, n = ch->recs.size();
+            if (base + n >= 0xFFFFFFF0ull) { fail("more than 2^32 records"); return; }
+            for (auto& r : ch->recs) if (r.mate != MGX_NO_MATE) r.mate += (uint32_t)base;        // slice-local -> global arrival index
+            if (n && mgx_sortdedup_upload_chunk(sd, base, n, ch->recs.data())) { fail(std::string("GPU: ") + mgx_last_error()); return; }
+            for (uint64_t k = 0; k < n; ++k) {
+                const uint32_t src = ch->input_index[k];
+                by_arrival.push_back(Kept{ch->blob.data() + ch->blob_off[src], (uint32_t)(ch->blob_off[src + 1] - ch->blob_off[src]),
+                                          ch->tid[src], (int32_t)ch->pos[src], ch->end[src], (ch->flag[src] & 4) == 0});
+            }
+            n_total += n;
+            std::vector<mgx_rec_t>().swap(ch->recs); std::vector<uint32_t>().swap(ch->input_index);
+            std::vector<uint16_t>().swap(ch->flag); std::vector<int32_t>().swap(ch->tid); std::vector<int64_t>().swap(ch->pos);
+            std::vector<int32_t>().swap(ch->end); std::vector<uint64_t>().swap(ch->blob_off);
+            kept_chunks.push_back(std::move(ch));
+            ++next_commit;
+        }
+    };
+    auto worker = [&]() {
+        for (;;) {
+            Slice sl;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return !queue.empty() || done_reading || failed.load(); });
+                if (failed.load() || (queue.empty() && done_reading)) return;
+                sl = std::move(queue.front());
+                queue.pop_front();
+                cv_room.notify_one();
+            }
+            std::unique_ptr<Chunk> ch(new Chunk);
+            parse_slice(sl.text, hdr, L, ch.get());
+            std::string().swap(sl.text);
+            if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
+            std::lock_guard<std::mutex> g(commit_mu);
+            ready.emplace(sl.seq, std::move(ch));
+            commit_ready();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+
+    // ---- reader: slices end where a queryname group ends
+    uint64_t seq = 0;
+    while (!failed.load()) {
+        if (carry.size() < slice_bytes && !eof) read_more(slice_bytes - carry.size());
+        if (carry.empty() && eof) break;
+        size_t cut;
+        if (eof) cut = carry.size();
+        else {
+            const size_t last_nl = carry.rfind('\n');
+            if (last_nl == std::string::npos) { read_more(slice_bytes); continue; }              // not even one full line yet
+            cut = last_group_start(carry.data(), last_nl + 1);
+            if (cut == 0) { read_more(slice_bytes); if (!eof) continue; cut = carry.size(); }     // one giant group: take more text
+        }
+        Slice sl;
+        sl.seq = seq++;
+        sl.text.assign(carry.data(), cut);
+        carry.erase(0, cut);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_room.wait(lk, [&] { return queue.size() < queue_cap || failed.load(); });
+        if (failed.load()) break;
+        queue.push_back(std::move(sl));
+        cv_work.notify_one();
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        done_reading = true;
+        cv_work.notify_all();
+    }
+    for (auto& th : pool) th.join();
+    if (in_path) fclose(f);
+    if (failed.load()) { fprintf(stderr, "%s\n", first_error.c_str()); return 1; }
+    const size_t n = (size_t)n_total;
+    printf("%zu alignment records, %zu reference sequences, %llu slices\n", n, hdr.ref_name.size(), (unsigned long long)seq);
+    time_stamp("read + parse + pair + upload done");
+
+    if (mgx_sortdedup_upload_end(sd, n)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
     std::vector<uint32_t> order(n); std::vector<uint8_t> dup(n);
-    if (mgx_sortdedup_sort_mark(sd, L, n, recs.data(), order.data(), dup.data())) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
+    if (mgx_sortdedup_run(sd) || mgx_sortdedup_results(sd, order.data(), dup.data())) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
     mgx_sortdedup_stats_t st{};
     mgx_sortdedup_stats(sd, &st);
     printf("double pairs %llu, single pairs %llu, records marked duplicate %llu, device pipeline %.3f ms\n",
@@ -170,8 +307,9 @@ int main(int argc, char** argv) {
     // ---- mark + compress + write
     std::vector<bamout::RecordRef> out(n);
     for (size_t q = 0; q < n; ++q) {
-        const uint32_t arrival = order[q], src = input_index[arrival];
-        out[q] = bamout::RecordRef{blob[src], blob_len[src], tid[src], (int32_t)pos[src], endv[src], dup[arrival] != 0, (flag[src] & 4) == 0};
+        const uint32_t arrival = order[q];
+        const Kept& k = by_arrival[arrival];
+        out[q] = bamout::RecordRef{k.blob, k.len, k.tid, k.beg, k.end, dup[arrival] != 0, k.mapped};
     }
     std::string err;
     if (!bamout::write_bam(out_path, hdr, out, threads, level, &err)) { fprintf(stderr, "write: %s\n", err.c_str()); return 1; }

@@ -113,6 +113,10 @@ struct mgx_pairhmm_batch {
     // timing: a ring of event sets, one set per run (4 per bin: f32 start/stop, f64 start/stop), so that
     // every run of a timed loop is measured and batch_stats can average them after the final sync
     std::vector<hipEvent_t> ev;
+    // what every class's fp32 event pair covers in the last run: its own launch, a whole multi-class launch (booked on
+    // the member with the most cells) or nothing (the other members)
+    std::vector<uint64_t> acct_cells, acct_bytes;
+    std::vector<int8_t> acct_multi;    // 0: single-class kernel, 1 + GSET: multi-class kernel
     uint32_t ev_sets = 0;          // sets allocated
     uint32_t runs_timed = 0;       // runs recorded since the last batch_stats
     hipEvent_t done = nullptr;     // recorded on the compute stream behind the last kernel of a run
@@ -931,6 +935,60 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         hipLaunchKernelGGL(f, dim3(grid), dim3(block), lds, sk, a);
         return 0;
     };
+    // Several narrow classes: one multi-class launch per lane-width set instead of one launch per class
+    // (MGX_PAIRHMM_MULTI=0 keeps the per-class launches).
+    static const int multi_mode = [] { const char* e = getenv("MGX_PAIRHMM_MULTI"); return e ? atoi(e) : 1; }();   // 2: occupancy-4 build
+    const bool multi_ok = multi_mode != 0;
+    std::vector<char> in_multi(b->bins.size(), 0);
+    b->acct_cells.assign(b->bins.size(), 0); b->acct_bytes.assign(b->bins.size(), 0); b->acct_multi.assign(b->bins.size(), 0);
+    for (size_t k = 0; k < b->bins.size(); ++k) { b->acct_cells[k] = b->bins[k].cells; b->acct_bytes[k] = b->bins[k].alg_bytes; }
+    if (multi_ok && !force_f64 && n_str == 1) {
+        for (int gset = 0; gset < 2; ++gset) {
+            std::vector<size_t> set;
+            for (size_t k = 0; k < b->bins.size(); ++k) {
+                const Bin& bn = b->bins[k];
+                if (narrow(bn) && bn.block == 64 && (gset == 0 ? bn.G == 16 : bn.G < 16)) set.push_back(k);
+            }
+            if (set.size() < 2 || set.size() > (size_t)kMultiBins) continue;
+            // most rows per lane first (the costliest workgroups), wider groups first among equals
+            std::stable_sort(set.begin(), set.end(), [&](size_t x, size_t y) {
+                const Bin &bx = b->bins[x], &by = b->bins[y];
+                return bx.RPL != by.RPL ? bx.RPL > by.RPL : bx.G > by.G;
+            });
+            MultiArgs m{};
+            m.a = base;
+            m.a.rerun_list = b->d_rerun_list; m.a.rerun_count = b->d_rerun_count + kSharedCount;
+            m.a.job_list = nullptr; m.a.n_dyn = nullptr;
+            m.a.ph2pr = c->d_ph2pr_f; m.a.mm = c->d_mm_f; m.a.ph2pr_div3 = c->d_div3_f; m.a.gap_ratio = c->d_ratio_f;
+            m.n_bins = (uint32_t)set.size();
+            uint32_t blocks = 0, lds = 0;
+            size_t book = set[0];
+            uint64_t cells = 0, bytes = 0;
+            for (size_t q = 0; q < set.size(); ++q) {
+                const Bin& bn = b->bins[set[q]];
+                m.block_first[q] = blocks; blocks += bn.grid_f32;
+                m.job_first[q] = bn.job_begin; m.job_count[q] = bn.job_count; m.lds_stride[q] = bn.lds_stride;
+                m.G[q] = (uint8_t)bn.G; m.RPL[q] = (uint8_t)bn.RPL;
+                lds = std::max(lds, lds_bytes(bn, true));
+                if (bn.cells > b->bins[book].cells) book = set[q];
+                cells += bn.cells; bytes += bn.alg_bytes;
+                in_multi[set[q]] = 1;
+                b->acct_cells[set[q]] = 0; b->acct_bytes[set[q]] = 0;
+            }
+            m.block_first[set.size()] = blocks;
+            b->acct_cells[book] = cells; b->acct_bytes[book] = bytes; b->acct_multi[book] = (int8_t)(1 + gset);
+            if (timing) for (size_t q : set) if (q != book) { HIP_TRY(hipEventRecord(ev[4 * q + 0], s)); HIP_TRY(hipEventRecord(ev[4 * q + 1], s)); }
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * book + 0], s));
+            if (multi_mode == 2) {
+                if (gset == 0) hipLaunchKernelGGL(pairhmm_fwd_multi_occ4<0>, dim3(blocks), dim3(64), lds, s, m);
+                else           hipLaunchKernelGGL(pairhmm_fwd_multi_occ4<1>, dim3(blocks), dim3(64), lds, s, m);
+            } else {
+                if (gset == 0) hipLaunchKernelGGL(pairhmm_fwd_multi<0>, dim3(blocks), dim3(64), lds, s, m);
+                else           hipLaunchKernelGGL(pairhmm_fwd_multi<1>, dim3(blocks), dim3(64), lds, s, m);
+            }
+            if (timing) HIP_TRY(hipEventRecord(ev[4 * book + 1], s));
+        }
+    }
     for (size_t at = 0; at < order.size(); ++at) {
         const size_t k = order[at];
         const Bin& bin = b->bins[k];
@@ -941,7 +999,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         a.rerun_count = b->d_rerun_count + (shared ? kSharedCount : (int)k);
         a.lds_stride = bin.lds_stride;
         a.job_first = bin.job_begin;
-        if (!force_f64) {
+        if (!force_f64 && !in_multi[k]) {
             a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count;
             a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f; a.ph2pr_div3 = c->d_div3_f; a.gap_ratio = c->d_ratio_f;
             KernelFn f = pick_kernel<float>(bin.G, bin.RPL);
@@ -1018,8 +1076,10 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, mgx_pairhm
     if ((c->flags & MGX_PAIRHMM_TIMING) && b->ran && !b->ev.empty() && b->runs_timed) {
         // mean over the runs recorded since the previous call (the ring keeps the last ev_sets of them)
         const uint32_t n_sets = std::min(b->runs_timed, b->ev_sets);
+        const bool acct = b->acct_cells.size() == b->bins.size();
+        auto cells_of = [&](size_t k) { return acct ? b->acct_cells[k] : b->bins[k].cells; };
         size_t dom = 0;
-        for (size_t k = 0; k < b->bins.size(); ++k) if (b->bins[k].cells >= b->bins[dom].cells) dom = k;
+        for (size_t k = 0; k < b->bins.size(); ++k) if (cells_of(k) >= cells_of(dom)) dom = k;
         double f32 = 0, f64 = 0, domms = 0;
         for (uint32_t q = 0; q < n_sets; ++q) {
             const uint32_t set = (b->runs_timed - 1 - q) % b->ev_sets;
@@ -1040,9 +1100,10 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, mgx_pairhm
         st.ms_f32 = (float)(f32 / n_sets); st.ms_f64 = (float)(f64 / n_sets);
         if (!force_f64) {
             st.ms_f32_dominant = (float)(domms / n_sets);
-            st.dominant_cells = b->bins[dom].cells;
-            st.dominant_alg_bytes = b->bins[dom].alg_bytes;
-            snprintf(st.dominant_kernel, sizeof st.dominant_kernel, "pairhmm_fwd<float, %d, %d>", b->bins[dom].G, b->bins[dom].RPL);
+            st.dominant_cells = cells_of(dom);
+            st.dominant_alg_bytes = acct ? b->acct_bytes[dom] : b->bins[dom].alg_bytes;
+            if (acct && b->acct_multi[dom]) snprintf(st.dominant_kernel, sizeof st.dominant_kernel, "pairhmm_fwd_multi<%d>", b->acct_multi[dom] - 1);
+            else snprintf(st.dominant_kernel, sizeof st.dominant_kernel, "pairhmm_fwd<float, %d, %d>", b->bins[dom].G, b->bins[dom].RPL);
         }
         b->runs_timed = 0;
     }

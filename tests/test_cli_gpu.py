@@ -135,15 +135,24 @@ def reg2bin(beg, end):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_templates,threads", [(1200, 4), (150, 1)])
-def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads):
+@pytest.mark.parametrize("n_templates,threads,slice_bytes,stdin", [(1200, 4, 0, False), (150, 1, 0, False), (1200, 3, 4096, False), (600, 2, 1500, True)])
+def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads, slice_bytes, stdin):
+    """slice_bytes > 0 forces the streaming ingest to cut the text into many slices (each ending on a queryname-group
+    boundary) that are parsed out of order and committed in order; the result must not depend on it."""
     raw = synth.gen_sortdedup_raw(n_templates, 41 + n_templates, n_contigs=3, contig_len=120000, dup_rate=0.3)
     sam, bam = str(tmp_path / "in.sam"), str(tmp_path / "out.bam")
     header, names, recs = make_sam(raw, sam)
     open(bam, "w").write("stale")                            # the tool must replace an existing file
-    res = subprocess.run([build_cli(), "-I", sam, "-O", bam, "-t", str(threads)], capture_output=True, text=True)
+    cmd = [build_cli(), "-O", bam, "-t", str(threads)] + (["-s", str(slice_bytes)] if slice_bytes else [])
+    if stdin:
+        res = subprocess.run(cmd, stdin=open(sam, "rb"), capture_output=True, text=True)
+    else:
+        res = subprocess.run(cmd + ["-I", sam], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert "sort + duplicate search done" in res.stdout
+    if slice_bytes:
+        n_slices = int(res.stdout.split(" slices")[0].split()[-1])
+        assert n_slices > 20
     text, refs, got = decode_bam(bam)
     assert text == header
     assert refs == [(n, int(l)) for n, l in zip(names, raw["target_len"])]
