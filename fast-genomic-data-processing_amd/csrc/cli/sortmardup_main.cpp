@@ -261,17 +261,19 @@ int main(int argc, char** argv) {
 
     // ---- reader: slices end where a queryname group ends
     uint64_t seq = 0;
+    size_t window = slice_bytes;                             // grows only while one queryname group fills the whole window
     while (!failed.load()) {
-        if (carry.size() < slice_bytes && !eof) read_more(slice_bytes - carry.size());
+        if (carry.size() < window && !eof) read_more(window - carry.size());
         if (carry.empty() && eof) break;
         size_t cut;
-        if (eof) cut = carry.size();
+        if (eof && carry.size() <= window) cut = carry.size();
         else {
-            const size_t last_nl = carry.rfind('\n');
-            if (last_nl == std::string::npos) { read_more(slice_bytes); continue; }              // not even one full line yet
-            cut = last_group_start(carry.data(), last_nl + 1);
-            if (cut == 0) { read_more(slice_bytes); if (!eof) continue; cut = carry.size(); }     // one giant group: take more text
+            const size_t limit = std::min(carry.size(), window);
+            const size_t last_nl = carry.rfind('\n', limit - 1);
+            cut = last_nl == std::string::npos ? 0 : last_group_start(carry.data(), last_nl + 1);
+            if (cut == 0) { window *= 2; continue; }         // not one complete group in the window yet: look at more text
         }
+        window = slice_bytes;
         Slice sl;
         sl.seq = seq++;
         sl.text.assign(carry.data(), cut);

@@ -38,8 +38,10 @@ namespace {
 // cell), many lanes waste steps on fill/drain (G - 1 per pair) and lanes on padding (up to G - 1 rows), so short
 // reads take narrow groups: G = 4 up to 32 bases, G = 8 up to 64, G = 16 up to 192 (1..12 rows per lane: the
 // common 100-151 bp reads), G = 64 with 4..16 rows per lane beyond that (up to 1024 bases).
-constexpr int kNarrowMaxRPL = 8, kG16MaxRPL = 12, kG64MinRPL = 4, kG64MaxRPL = 16;
-constexpr int kMaxRowsG4 = 4 * kNarrowMaxRPL, kMaxRowsG8 = 8 * kNarrowMaxRPL;
+// (Giving 8 lanes up to 16 rows each -- reads up to 128 bases -- was measured and lost: 128 x 256 test cases 6019 ->
+// 5642 GCUPS, ragged 4429 -> 3835; profiles/r02_pairhmm_g8_rows.txt.)
+constexpr int kNarrowMaxRPL = 8, kG8MaxRPL = 8, kG16MaxRPL = 12, kG64MinRPL = 4, kG64MaxRPL = 16;
+constexpr int kMaxRowsG4 = 4 * kNarrowMaxRPL, kMaxRowsG8 = 8 * kG8MaxRPL;
 constexpr int kMaxRowsG16 = 16 * kG16MaxRPL;
 constexpr int kMaxRowsG64 = 64 * kG64MaxRPL;
 constexpr uint32_t kMaxLdsPerBlock = 64 * 1024;
@@ -154,8 +156,9 @@ int upload(T** dst, const void* src, size_t bytes, hipStream_t s) {
 // (G, RPL) class of a read of R rows; G = 0 if unsupported.  MGX_PAIRHMM_MIN_G=16 switches the narrow groups off.
 inline void shape_of(uint32_t R, int* G, int* RPL) {
     static const int min_g = [] { const char* e = getenv("MGX_PAIRHMM_MIN_G"); const int v = e ? atoi(e) : 4; return v; }();
+    const uint32_t g8_rows = (uint32_t)kMaxRowsG8;
     if (R <= (uint32_t)kMaxRowsG4 && min_g <= 4) { *G = 4; *RPL = (int)((R + 3) / 4); }
-    else if (R <= (uint32_t)kMaxRowsG8 && min_g <= 8) { *G = 8; *RPL = (int)((R + 7) / 8); }
+    else if (R <= g8_rows && min_g <= 8) { *G = 8; *RPL = (int)((R + 7) / 8); }
     else if (R <= (uint32_t)kMaxRowsG16) { *G = 16; *RPL = (int)((R + 15) / 16); }
     else if (R <= (uint32_t)kMaxRowsG64) { *G = 64; *RPL = std::max(kG64MinRPL, (int)((R + 63) / 64)); }
     else { *G = 0; *RPL = 0; }
@@ -167,7 +170,7 @@ inline uint32_t lds_bytes(const Bin& bin, bool f32) {
     return waves * etab + groups * bin.lds_stride;
 }
 // bins in order of (G, RPL): [G=4: 1..8][G=8: 1..8][G=16: 1..12][G=64: 4..16]
-constexpr int kBinG8 = kNarrowMaxRPL, kBinG16 = 2 * kNarrowMaxRPL, kBinG64 = kBinG16 + kG16MaxRPL;
+constexpr int kBinG8 = kNarrowMaxRPL, kBinG16 = kBinG8 + kG8MaxRPL, kBinG64 = kBinG16 + kG16MaxRPL;
 constexpr int kBins = kBinG64 + (kG64MaxRPL - kG64MinRPL + 1);
 inline int bin_index(int G, int RPL) {
     return G == 4 ? RPL - 1 : G == 8 ? kBinG8 + RPL - 1 : G == 16 ? kBinG16 + RPL - 1 : kBinG64 + RPL - kG64MinRPL;
@@ -179,7 +182,8 @@ inline void bin_shape(int k, Bin* b) {
     else { b->G = 64; b->RPL = k - kBinG64 + kG64MinRPL; }
     // the fp64 kernel keeps twice the registers per row: beyond 8 rows per lane of 16 it runs one
     // pair per wavefront instead
-    if (b->G == 16 && b->RPL > 8) { b->Gd = 64; b->RPLd = (16 * b->RPL + 63) / 64; } else { b->Gd = b->G; b->RPLd = b->RPL; }
+    if (b->G == 16 && b->RPL > 8) { b->Gd = 64; b->RPLd = (16 * b->RPL + 63) / 64; }
+    else { b->Gd = b->G; b->RPLd = b->RPL; }
 }
 constexpr uint64_t kMergeBelow = 4096;
 
@@ -909,7 +913,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     // Re-runs in double precision: the "narrow" classes (at most 16 lanes x 8 rows: every read up to 128 bases) append
     // to ONE list (their jobs are a prefix of the job array) that ONE fp64 launch of the 16 x RPLd shape processes --
     // a test case's value does not depend on the shape that computes it; wider classes keep a list and a launch each.
-    auto narrow = [](const Bin& bn) { return bn.G <= 16 && bn.RPL <= kNarrowMaxRPL; };
+    auto narrow = [](const Bin& bn) { return bn.G <= 16 && bn.G * bn.RPL <= 16 * kNarrowMaxRPL; };
     uint32_t n_narrow_jobs = 0, narrow_max_h = 0, narrow_rows = 0;
     size_t first_narrow = b->bins.size();
     for (size_t k = 0; k < b->bins.size(); ++k) {
@@ -937,7 +941,14 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     };
     // Several narrow classes: one multi-class launch per lane-width set instead of one launch per class
     // (MGX_PAIRHMM_MULTI=0 keeps the per-class launches).
-    static const int multi_mode = [] { const char* e = getenv("MGX_PAIRHMM_MULTI"); return e ? atoi(e) : 1; }();   // 2: occupancy-4 build
+    // Only SMALL classes share a launch: measured on an MI355X (profiles/r02_pairhmm_multi_ab.txt) the common launch
+    // costs every class the register budget of the hungriest one (131-149 VGPRs: 3 wavefronts per SIMD; 4 when forced,
+    // with spills), which outweighs the saved drains for classes that fill the device on their own (ragged 1 M test
+    // cases, nine classes of ~29 000 workgroups: 4462 -> 4343 GCUPS) but not for classes of a few thousand workgroups
+    // (reads of 20-32 bases: 2764 -> 3009; region-sized batches).  MGX_PAIRHMM_MULTI: 0 never, 1 small classes (default),
+    // 2 the same with the build forced to 4 wavefronts per SIMD, 3 every narrow class.
+    static const int multi_mode = [] { const char* e = getenv("MGX_PAIRHMM_MULTI"); return e ? atoi(e) : 1; }();
+    const uint32_t multi_below = multi_mode == 3 ? 0xFFFFFFFFu : (uint32_t)c->n_cu * 64u;     // workgroups; ~5 device fills
     const bool multi_ok = multi_mode != 0;
     std::vector<char> in_multi(b->bins.size(), 0);
     b->acct_cells.assign(b->bins.size(), 0); b->acct_bytes.assign(b->bins.size(), 0); b->acct_multi.assign(b->bins.size(), 0);
@@ -947,7 +958,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             std::vector<size_t> set;
             for (size_t k = 0; k < b->bins.size(); ++k) {
                 const Bin& bn = b->bins[k];
-                if (narrow(bn) && bn.block == 64 && (gset == 0 ? bn.G == 16 : bn.G < 16)) set.push_back(k);
+                if (narrow(bn) && bn.RPL <= kNarrowMaxRPL && bn.block == 64 && bn.grid_f32 < multi_below && (gset == 0 ? bn.G == 16 : bn.G < 16)) set.push_back(k);
             }
             if (set.size() < 2 || set.size() > (size_t)kMultiBins) continue;
             // most rows per lane first (the costliest workgroups), wider groups first among equals
