@@ -95,7 +95,9 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backe
     route_s, shard_info = 0.0, None
     t0 = time.perf_counter()
     if world == 1:
-        eng.upload(L, recs)
+        eng.upload(L, recs)                # first use: allocates the device buffers and the pinned staging
+        t0 = time.perf_counter()
+        eng.upload(L, recs)                # the upload that is timed: packed host records -> HBM, steady state
     else:
         routed = pkg.Routed(L, recs, world, only_shard=rank)
         route_s = time.perf_counter() - t0
@@ -441,9 +443,16 @@ def main():
     # ---- the same shard through the host work queue: host buffers in, results in host memory out (PCIe-inclusive;
     # never `value`).  Lanes pack / upload batch k+1 while the kernels of batch k run.
     lanes = args.queue_lanes or max(2, min(8, host_cores() // world))      # the ranks of a node share its cores
+    if world == 1:
+        # at one GPU the resident batch is configs[1] (1M test cases); the queue is measured on a longer stream of the
+        # same distribution (4M test cases = 64 batches) so that it reaches its steady state
+        del d
+        n_local = max(total, 4 << 20)
+        d = synth.gen_pairhmm_pairs_fast(n_local, seed)
+    else:
+        n_local = hi - lo
     q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
     prepared = pkg.pairhmm.make_input(d)
-    n_local = hi - lo
     q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared)      # warm-up: pinned slabs are allocated on first use
     barrier()
     t0 = time.perf_counter()
@@ -452,14 +461,15 @@ def main():
     qdt = max_over_ranks(time.perf_counter() - t0)
     qst = q.stats()
     q.close()
+    q_total = n_local if world == 1 else total
     if rank == 0:
-        line["queue"] = {"value": total * 128 * 256 / qdt / 1e9, "unit": "GCUPS", "seconds": qdt, "pcie_inclusive": True,
-                         "lanes_per_gpu": lanes, "depth": 2, "batch_pairs": 65536, "batches_per_gpu": qst["n_batches"],
+        line["queue"] = {"value": q_total * 128 * 256 / qdt / 1e9, "unit": "GCUPS", "seconds": qdt, "pcie_inclusive": True,
+                         "test_cases": q_total, "lanes_per_gpu": lanes, "depth": 2, "batch_pairs": 65536, "batches_per_gpu": qst["n_batches"],
                          "h2d_GBps_per_gpu": qst["bytes_h2d"] / qst["seconds"] / 1e9, "pack_s_per_lane": qst["pack_seconds"] / lanes,
                          "wait_s_per_lane": qst["wait_seconds"] / lanes,
-                         "note": "one pass of the host work queue over this rank's shard: pack (gather + bin) -> pinned slab -> H2D -> kernels "
+                         "note": "one pass of the host work queue over this rank's stream: pack (gather + bin) -> pinned slab -> H2D -> kernels "
                                  "-> D2H, results in host memory; bounded by the PCIe link at 900 bytes per 128x256 test case"}
-        # the streamed results are the resident batch's results
+        # the streamed results are the single call's results
         chk = eng.compute(pkg.pairhmm.pack_batch(d, n_local - 4096, n_local))
         line["queue"]["identical_to_single_call"] = bool(np.array_equal(chk, qout[n_local - 4096:]))
     del qout

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -130,6 +131,7 @@ struct BuildOut {
     u64* nk; u32* nrec;                   // near double pairs: one key word p1 << 32 | orient << 30 | (p2 - p1) << 16 | inverted pair score
     int near_enabled;
     u32 mate_flag;                        // 0x80000000 when record indices leave bit 31 free: "the mate is the neighbour rec ^ 1"
+    u32* half_hist;                       // [workgroups][256]: histogram of the coordinate's low byte (first digit of the record sort), or NULL
 };
 
 // Entries are compacted with one global atomic per workgroup and kind, so their order is not the
@@ -146,9 +148,11 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
     constexpr int ITEMS = kBuildBlock / 256;
     __shared__ u64 smax[4][5];
     __shared__ u32 s_cnt[3], s_base[3];
+    __shared__ u32 s_hist[256];
     const u32 base = blockIdx.x * kBuildBlock;
     const u64 lt = lanemask_lt();
     if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    s_hist[threadIdx.x] = 0;
     __syncthreads();
 
     u64 coord[ITEMS], p5[ITEMS];
@@ -185,6 +189,9 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
                 o.ckey[i] = o.packed_coord ? (coord[k] << 32) | i : coord[k];
                 if (!o.packed_coord) o.cval[i] = i;
                 m_coord = max(m_coord, coord[k]);
+                // the record sort's first digit is the coordinate's low byte in either key form: its per-tile
+                // histogram is gathered here, where the keys are made, instead of by a pass that re-reads them
+                if (o.half_hist) atomicAdd(&s_hist[(u32)coord[k] & 255u], 1u);
             }
             if (!(flag[k] & kIgnorable)) c = mate[k] == MGX_NO_MATE ? 2 : (mate[k] > i ? 1 : 0);
             if (c == 1) {
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(256) void k_build_emit(const mgx_rec_t* __restrict_
         slot[k] = c == 1 ? based + (u32)__popcll(bd & lt) : c == 2 ? bases + (u32)__popcll(bs & lt) : basen + (u32)__popcll(bn & lt);
     }
     __syncthreads();
+    if (o.half_hist) o.half_hist[(size_t)blockIdx.x * 256 + threadIdx.x] = s_hist[threadIdx.x];
     if (threadIdx.x < 3) {
         const u32 cnt = s_cnt[threadIdx.x];
         u32* dst = threadIdx.x == 0 ? &sc->n_double : threadIdx.x == 1 ? &sc->n_single : &sc->n_near;
@@ -334,6 +342,19 @@ __global__ __launch_bounds__(256) void k_radix_hist(const u64* __restrict__ keys
     }
     __syncthreads();
     hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];     // tile-major: coalesced
+}
+
+// first pass of the record sort: the build kernel's half-tile histograms (kBuildBlock records each) -> tile histograms
+template <int TILE>
+__global__ __launch_bounds__(256) void k_hist_merge(const u32* __restrict__ half, u32 n_half, u32* __restrict__ hist) {
+    constexpr int RATIO = TILE / kBuildBlock;
+    u32 v = 0;
+#pragma unroll
+    for (int k = 0; k < RATIO; ++k) {
+        const u32 hb = blockIdx.x * RATIO + k;
+        if (hb < n_half) v += half[(size_t)hb * 256 + threadIdx.x];
+    }
+    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = v;
 }
 
 // column sums per chunk of kChunkTiles tiles
@@ -1051,6 +1072,7 @@ struct mgx_sortdedup {
     u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
     u32* d_sub_start = nullptr; size_t sub_cap = 0;      // first near entry per kNearSpan positions (bitmap pass)
     uint8_t* d_dup = nullptr;
+    u32* d_half_hist = nullptr;            // [ceil(n / kBuildBlock)][256], written by the build kernel
     Scalars* d_sc = nullptr;
     void* pinned[2] = {nullptr, nullptr};
     size_t pinned_cap = 0;
@@ -1087,6 +1109,7 @@ void free_buffers(mgx_sortdedup* c) {
     }
     for (auto& q : c->scr) { (void)hipFree(q.hist); (void)hipFree(q.chunk); (void)hipFree(q.longl); (void)hipFree(q.multi); q.hist = q.chunk = q.longl = q.multi = nullptr; }
     (void)hipFree(c->d_dup); c->d_dup = nullptr;
+    (void)hipFree(c->d_half_hist); c->d_half_hist = nullptr;
     c->cap = 0;
 }
 
@@ -1115,6 +1138,7 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
         rc |= dalloc(&q.multi, n / 2 + 16);          // heads of runs with >= 2 entries
     }
     rc |= dalloc(&c->d_dup, n);
+    rc |= dalloc(&c->d_half_hist, (n / kBuildBlock + 2) * 256);
     if (rc) { free_buffers(c); return -ENOMEM; }
     c->cap = n;
     return 0;
@@ -1124,7 +1148,7 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
 // buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
 template <int WAVES>
 int radix_sort_w(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q, u64* key[2], u64* p64[2], u32* p32[2], u32 n,
-                 int first_shift, int bits, int* cur, u32* low32_out, bool* low32_done) {
+                 int first_shift, int bits, int* cur, u32* low32_out, bool* low32_done, const u32* first_half_hist) {
     constexpr int TILE = WAVES * 64 * kItems;
     if (low32_done) *low32_done = false;
     if (n == 0) return 0;
@@ -1132,7 +1156,10 @@ int radix_sort_w(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& 
     const u32 n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
     for (int shift = first_shift; shift < first_shift + bits; shift += 8) {
         const int in = *cur, out = in ^ 1;
-        hipLaunchKernelGGL(k_radix_hist<TILE>, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, q.hist);
+        if (first_half_hist && shift == first_shift)
+            hipLaunchKernelGGL(k_hist_merge<TILE>, dim3(n_tiles), dim3(256), 0, s, first_half_hist, (n + kBuildBlock - 1) / kBuildBlock, q.hist);
+        else
+            hipLaunchKernelGGL(k_radix_hist<TILE>, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, q.hist);
         hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
         hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, s, q.chunk, n_chunks);
         hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
@@ -1167,13 +1194,13 @@ int radix_sort_w(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& 
 // one stable LSD radix sort of (key, [p64], p32) over `bits` low bits of the key
 // buffers are ping-pong pairs; *cur is the index of the input buffer and is updated
 int radix_sort(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& q, u64* key[2], u64* p64[2], u32* p32[2], u32 n,
-               int first_shift, int bits, int* cur, u32* low32_out = nullptr, bool* low32_done = nullptr) {
+               int first_shift, int bits, int* cur, u32* low32_out = nullptr, bool* low32_done = nullptr, const u32* first_half_hist = nullptr) {
     // 8192-key tiles (MGX_SORTDEDUP_WIDE_TILES=1) were meant to double the payload run a digit leaves the tile with;
     // measured on an MI355X at 200 M records they LOSE: whole pipeline 10.73 ms against 10.15 ms with 4096-key tiles
     // (64 KB of LDS per workgroup leaves two workgroups per CU), so the default stays 4096
     const bool wide = c->wide_tiles > 0;
-    return wide ? radix_sort_w<8>(c, s, q, key, p64, p32, n, first_shift, bits, cur, low32_out, low32_done)
-                : radix_sort_w<kScatterWaves>(c, s, q, key, p64, p32, n, first_shift, bits, cur, low32_out, low32_done);
+    return wide ? radix_sort_w<8>(c, s, q, key, p64, p32, n, first_shift, bits, cur, low32_out, low32_done, first_half_hist)
+                : radix_sort_w<kScatterWaves>(c, s, q, key, p64, p32, n, first_shift, bits, cur, low32_out, low32_done, first_half_hist);
 }
 
 // duplicate search over one sorted entry array: run heads -> dense list -> marks (+ long runs)
@@ -1340,9 +1367,15 @@ int ensure_staging(mgx_sortdedup_t* c, size_t chunk) {
 }
 
 int upload_threads() {
-    // one core copies ~12 GB/s into the staging buffer, less than a quarter of what the link takes:
-    // split every piece over a few threads (MGX_UPLOAD_THREADS, default 4)
-    static const int n_thr = [] { const char* e = getenv("MGX_UPLOAD_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    // one core moves ~12 GB/s into the staging buffer, less than a quarter of what the link takes: every piece is
+    // split over several threads (MGX_UPLOAD_THREADS; default half the cores, at most 8 -- with 4 the 24-byte
+    // conversion, not the link, bounded the upload: 200 M records in 0.133 s; measured on the GPU box)
+    static const int n_thr = [] {
+        const char* e = getenv("MGX_UPLOAD_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int v = e ? atoi(e) : std::max(2, std::min(8, hw / 2));
+        return v < 1 ? 1 : (v > 16 ? 16 : v);
+    }();
     return n_thr;
 }
 
@@ -1395,14 +1428,20 @@ int stream_up_recs(mgx_sortdedup_t* c, uint64_t first, uint64_t n, const mgx_rec
         mgx_rec_t* dst = c->d_recs + first + off;
         bool compact = compact_ok;
         if (compact) {
-            Wire24* w = static_cast<Wire24*>(c->pinned[buf]);
+            // a wire record is the low halves of the two 64-bit fields followed by the record's second 16 bytes as
+            // they are: four 8-byte loads and three 8-byte stores per record, as cheap as the plain copy
+            uint64_t* w = static_cast<uint64_t*>(c->pinned[buf]);
+            const uint64_t* s64 = reinterpret_cast<const uint64_t*>(src);
+            static_assert(sizeof(mgx_rec_t) == 32 && offsetof(mgx_rec_t, prime5) == 8 && offsetof(mgx_rec_t, mate) == 16, "record layout");
             std::atomic<uint64_t> high{0};
-            split_over_threads(m, 65536, [&, w, src](size_t a, size_t b) {
+            split_over_threads(m, 65536, [&, w, s64](size_t a, size_t b) {
                 uint64_t hi = 0;
                 for (size_t i = a; i < b; ++i) {
-                    const mgx_rec_t r = src[i];
-                    hi |= r.coord | r.prime5;
-                    w[i] = Wire24{(u32)r.coord, (u32)r.prime5, r.mate, r.flag, r.score, r.tile, r.x, r.y, 0};
+                    const uint64_t c0 = s64[4 * i], p0 = s64[4 * i + 1];
+                    hi |= c0 | p0;
+                    w[3 * i] = (c0 & 0xFFFFFFFFull) | (p0 << 32);
+                    w[3 * i + 1] = s64[4 * i + 2];
+                    w[3 * i + 2] = s64[4 * i + 3];
                 }
                 if (hi >> 32) high.fetch_or(1);
             });
@@ -1512,7 +1551,8 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
             const u32 nb = (n + kBuildBlock - 1) / kBuildBlock;
             BuildOut o{c->sharded ? nullptr : c->d_ckey[0], c->d_cval[0], c->d_k1[0], c->d_k2[0], c->d_prec[0], c->d_sk1[0], c->d_srec[0],
                        c->d_indicator, c->indicator_bits, c->L, c->packed_coord ? 1 : 0, c->packed_pair ? 1 : 0,
-                       c->d_nk[0], c->d_nrec[0], c->packed_pair ? 1 : 0, n < 0x80000000u ? 0x80000000u : 0u};
+                       c->d_nk[0], c->d_nrec[0], c->packed_pair ? 1 : 0, n < 0x80000000u ? 0x80000000u : 0u,
+                       c->sharded ? nullptr : c->d_half_hist};
             hipLaunchKernelGGL(k_build_emit, dim3(nb), dim3(256), 0, s, c->d_recs, n, o, c->d_sc);
             HIP_TRY(hipGetLastError());
         }
@@ -1599,11 +1639,13 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     const uint64_t bytes_before_records = c->scatter_bytes;
     if (c->packed_coord) {
         // key = coord << 32 | arrival index: sort on the high half only, 8 bytes per record per pass
-        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n_order, 32, bits_of(c->sc.max_coord), &ccur, c->d_cval[0], &unpacked))) return rc;
+        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, nullptr, n_order, 32, bits_of(c->sc.max_coord), &ccur, c->d_cval[0], &unpacked,
+                             c->sharded ? nullptr : c->d_half_hist))) return rc;
         if (n_order && !unpacked) hipLaunchKernelGGL(k_unpack_order, dim3((n_order + 255) / 256), dim3(256), 0, sR, c->d_ckey[ccur], n_order, c->d_cval[0]);
         ccur = 0;
     } else {
-        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, c->d_cval, n_order, 0, bits_of(c->sc.max_coord), &ccur))) return rc;
+        if ((rc = radix_sort(c, sR, c->scr[2], c->d_ckey, nullptr, c->d_cval, n_order, 0, bits_of(c->sc.max_coord), &ccur, nullptr, nullptr,
+                             c->sharded ? nullptr : c->d_half_hist))) return rc;
     }
     c->order_buf = ccur;
     c->ev_rec_end = c->ev_used;

@@ -428,6 +428,41 @@ def gen_sortdedup_packed_fast(n_records, seed, n_contigs=25, contig_len=124_000_
     return (rec[:n_records] if 2 * n_t >= n_records else rec), L
 
 
+def raw_from_packed(recs, n_contigs=25, contig_len=124_000_000, read_len=150, seed=1):
+    """Parsed-record arrays (the layout of mgx_raw_records_t) for the packed records of gen_sortdedup_packed: what a
+    SAM/BAM reader would hold for them -- contig + position, a CIGAR with the soft clip that separates the
+    coordinate from the 5' end, qualities, an Illumina queryname shared by a template's records.  Vectorised; used
+    to time the reference's own classes on a sample of the benchmark workload."""
+    n = len(recs)
+    L = n_contigs * contig_len
+    coord = recs["coord"].astype(np.int64)
+    mapped = (recs["flag"] & 4) == 0
+    tid = np.where(coord < L, coord // contig_len, -1).astype(np.int32)
+    pos = np.where(coord < L, coord % contig_len, -1).astype(np.int64)
+    rev = (recs["flag"] & 16) != 0
+    clip = np.clip(np.where(rev, 0, coord - recs["prime5"].astype(np.int64)), 0, 20).astype(np.uint32)
+    clip = np.where(rev, (np.arange(n) * 7 % 23 < 3) * 5, clip).astype(np.uint32)
+    m = (read_len - clip).astype(np.uint32)
+    has_clip = clip > 0
+    n_ops = np.where(mapped, 1 + has_clip.astype(np.int64), 0)
+    cigar_off = np.zeros(n + 1, dtype=np.uint64); cigar_off[1:] = np.cumsum(n_ops)
+    cigar = np.zeros(int(cigar_off[-1]), dtype=np.uint32)
+    first = cigar_off[:-1].astype(np.int64)
+    fwd_clip = mapped & has_clip & ~rev; rev_clip = mapped & has_clip & rev; plain = mapped & ~has_clip
+    cigar[first[plain]] = (m[plain] << 4)
+    cigar[first[fwd_clip]] = (clip[fwd_clip] << 4) | 4; cigar[first[fwd_clip] + 1] = m[fwd_clip] << 4
+    cigar[first[rev_clip]] = m[rev_clip] << 4; cigar[first[rev_clip] + 1] = (clip[rev_clip] << 4) | 4
+    rng = np.random.default_rng(seed)
+    qual = rng.integers(2, 42, size=n * read_len, dtype=np.uint8)
+    qual_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len))
+    t = np.arange(n, dtype=np.int64) // 2
+    names = [b"SYN:1:FC:1:%d:%d:%d" % ((int(x) >> 32) & 0xFFFF, (int(x) >> 16) & 0xFFFF, int(x) & 0xFFFF) for x in t]
+    qname_off = np.zeros(n + 1, dtype=np.uint64); qname_off[1:] = np.cumsum([len(x) for x in names])
+    return dict(n_records=n, flag=recs["flag"].astype(np.uint16), tid=tid, pos=pos, cigar_off=cigar_off, cigar=cigar,
+                qual_off=qual_off, qual=qual, qname_off=qname_off, qname=np.frombuffer(b"".join(names), dtype=np.uint8).copy(),
+                n_targets=n_contigs, target_len=np.full(n_contigs, contig_len, dtype=np.uint64))
+
+
 def gen_sw_pairs(n_pairs, seed, ref_range=(40, 400), alt_range=(20, 250), strategies=(9, 10, 11, 12)):
     """Smith-Waterman workload: reference windows and alternates that are mutated sub-ranges of them
     (substitutions, insertions, deletions, random flanks), plus a share of unrelated sequences.
