@@ -370,6 +370,7 @@ def main():
     ap.add_argument("--queue-lanes", type=int, default=0, help="host lanes of the work queue (default: min(8, cores / ranks))")
     ap.add_argument("--no-ragged", action="store_true", help="skip sub-run 2b (ragged lengths)")
     ap.add_argument("--no-regions", action="store_true", help="skip the row-F1 leg (1000 regions of 40 x 25)")
+    ap.add_argument("--no-queue", action="store_true", help="skip the host-work-queue leg (counter-collection runs)")
     ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[4]: PairHMM queue and sort/mark-duplicate pipeline co-resident")
     args = ap.parse_args()
 
@@ -442,37 +443,38 @@ def main():
 
     # ---- the same shard through the host work queue: host buffers in, results in host memory out (PCIe-inclusive;
     # never `value`).  Lanes pack / upload batch k+1 while the kernels of batch k run.
-    lanes = args.queue_lanes or max(2, min(8, host_cores() // world))      # the ranks of a node share its cores
-    if world == 1:
-        # at one GPU the resident batch is configs[1] (1M test cases); the queue is measured on a longer stream of the
-        # same distribution (4M test cases = 64 batches) so that it reaches its steady state
-        del d
-        n_local = max(total, 4 << 20)
-        d = synth.gen_pairhmm_pairs_fast(n_local, seed)
-    else:
-        n_local = hi - lo
-    q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
-    prepared = pkg.pairhmm.make_input(d)
-    q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared)      # warm-up: pinned slabs are allocated on first use
-    barrier()
-    t0 = time.perf_counter()
-    qout = q.run(d, prepared=prepared)
-    barrier()
-    qdt = max_over_ranks(time.perf_counter() - t0)
-    qst = q.stats()
-    q.close()
-    q_total = n_local if world == 1 else total
-    if rank == 0:
-        line["queue"] = {"value": q_total * 128 * 256 / qdt / 1e9, "unit": "GCUPS", "seconds": qdt, "pcie_inclusive": True,
-                         "test_cases": q_total, "lanes_per_gpu": lanes, "depth": 2, "batch_pairs": 65536, "batches_per_gpu": qst["n_batches"],
-                         "h2d_GBps_per_gpu": qst["bytes_h2d"] / qst["seconds"] / 1e9, "pack_s_per_lane": qst["pack_seconds"] / lanes,
-                         "wait_s_per_lane": qst["wait_seconds"] / lanes,
-                         "note": "one pass of the host work queue over this rank's stream: pack (gather + bin) -> pinned slab -> H2D -> kernels "
-                                 "-> D2H, results in host memory; bounded by the PCIe link at 900 bytes per 128x256 test case"}
-        # the streamed results are the single call's results
-        chk = eng.compute(pkg.pairhmm.pack_batch(d, n_local - 4096, n_local))
-        line["queue"]["identical_to_single_call"] = bool(np.array_equal(chk, qout[n_local - 4096:]))
-    del qout
+    if not args.no_queue:
+        lanes = args.queue_lanes or max(2, min(8, host_cores() // world))      # the ranks of a node share its cores
+        if world == 1:
+            # at one GPU the resident batch is configs[1] (1M test cases); the queue is measured on a longer stream of the
+            # same distribution (4M test cases = 64 batches) so that it reaches its steady state
+            del d
+            n_local = max(total, 4 << 20)
+            d = synth.gen_pairhmm_pairs_fast(n_local, seed)
+        else:
+            n_local = hi - lo
+        q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
+        prepared = pkg.pairhmm.make_input(d)
+        q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared)      # warm-up: pinned slabs are allocated on first use
+        barrier()
+        t0 = time.perf_counter()
+        qout = q.run(d, prepared=prepared)
+        barrier()
+        qdt = max_over_ranks(time.perf_counter() - t0)
+        qst = q.stats()
+        q.close()
+        q_total = n_local if world == 1 else total
+        if rank == 0:
+            line["queue"] = {"value": q_total * 128 * 256 / qdt / 1e9, "unit": "GCUPS", "seconds": qdt, "pcie_inclusive": True,
+                             "test_cases": q_total, "lanes_per_gpu": lanes, "depth": 2, "batch_pairs": 65536, "batches_per_gpu": qst["n_batches"],
+                             "h2d_GBps_per_gpu": qst["bytes_h2d"] / qst["seconds"] / 1e9, "pack_s_per_lane": qst["pack_seconds"] / lanes,
+                             "wait_s_per_lane": qst["wait_seconds"] / lanes,
+                             "note": "one pass of the host work queue over this rank's stream: pack (gather + bin) -> pinned slab -> H2D -> kernels "
+                                     "-> D2H, results in host memory; bounded by the PCIe link at 900 bytes per 128x256 test case"}
+            # the streamed results are the single call's results
+            chk = eng.compute(pkg.pairhmm.pack_batch(d, n_local - 4096, n_local))
+            line["queue"]["identical_to_single_call"] = bool(np.array_equal(chk, qout[n_local - 4096:]))
+        del qout
 
     # ---- sub-run 2b: ragged lengths R in [32,128], H in [64,256]
     if not args.no_ragged:
@@ -494,7 +496,7 @@ def main():
         del d2
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(synth, 1 << 18, seed)
-    del d, prepared
+    d = prepared = None
     eng.close()
 
     # ---- second half of BASELINE.json's metric: sortmardup Mrecords/s (configs[3]) ------------

@@ -12,10 +12,11 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ph, sd, sw = pkg.PairHMMEngine(0), pkg.SortDedupEngine(0), pkg.SmithWatermanEngine(0)
 oph, osd, osw = PairHMMOracle(_ensure_oracle()), SortDedupOracle(), SmithWatermanOracle()
 rng = np.random.default_rng(seed0)
-t0 = time.time(); it = 0; fails = 0; counts = {"sort": 0, "pairhmm": 0, "regions": 0, "sw": 0}
+t0 = time.time(); it = 0; fails = 0; counts = {"sort": 0, "pairhmm": 0, "regions": 0, "sw": 0, "shards": 0, "queue": 0}
+queue = pkg.PairHMMQueue(devices=(0, 0), lanes_per_device=2, depth=2, batch_pairs=700)
 while time.time() - t0 < budget:
     seed = int(rng.integers(1, 2**31 - 1)); it += 1
-    kind = it % 4
+    kind = it % 6
     try:
         if kind == 0:
             kw = dict(n_contigs=int(rng.integers(1, 6)), contig_len=int(rng.choice([5000, 60000, 400000, 3000000])),
@@ -50,6 +51,39 @@ while time.time() - t0 < budget:
                 d2 = dict(dd); d2["pair_read"] = None; d2["pair_hap"] = None
                 ok &= bool(np.array_equal(g, ph.compute(d2).reshape(g.shape)))
             counts["regions"] += 1
+        elif kind == 4:
+            # one record set over 1..5 shards (router + shard upload + merge), streamed upload in random pieces
+            raw = synth.gen_sortdedup_raw(int(rng.integers(1, 6000)), seed, n_contigs=int(rng.integers(1, 5)), contig_len=int(rng.choice([4000, 50000, 900000])),
+                                          dup_rate=float(rng.choice([0.1, 0.4])), cross_contig_rate=float(rng.choice([0.0, 0.3])), frag_rate=float(rng.choice([0.05, 0.3])))
+            recs, idx, L = pkg.sortdedup.pack(raw)
+            wo, wd, _ = osd.run(L, recs)
+            k_shards = int(rng.integers(1, 6))
+            routed = pkg.Routed(L, recs, k_shards)
+            o = np.zeros(len(recs), dtype=np.uint32); d = np.zeros(len(recs), dtype=np.uint8)
+            for k in range(k_shards):
+                sd.upload_shard(routed, k); sd.run()
+                so, sdup = sd.results()
+                routed.merge(k, so, sdup, o, d)
+            routed.close()
+            ok = np.array_equal(o, wo) and np.array_equal(d, wd)
+            cuts = sorted(set([0, len(recs)] + [int(x) for x in rng.integers(0, len(recs) + 1, 4)]))
+            sd.upload_chunks(L, (recs[a:b] for a, b in zip(cuts, cuts[1:])), n_expected=int(rng.integers(0, len(recs) + 1)))
+            sd.run()
+            o2, d2 = sd.results()
+            ok &= bool(np.array_equal(o2, wo) and np.array_equal(d2, wd))
+            counts["shards"] += 1
+        elif kind == 5:
+            # the host work queue: a stream cut into small batches over two lanes x two "devices" equals one call
+            if it % 12 == 5:
+                d = synth.gen_pairhmm_region(int(rng.integers(1, 60)), int(rng.integers(1, 30)), seed, r_range=(1, int(rng.choice([60, 151]))), h_range=(1, 300))
+            else:
+                d = synth.gen_pairhmm_pairs(int(rng.integers(1, 6000)), seed, r_range=(1, int(rng.choice([40, 128, 200]))), h_range=(1, int(rng.choice([60, 256]))))
+            ok = bool(np.array_equal(queue.run(d), ph.compute(d)))
+            regs = [synth.gen_pairhmm_region(int(rng.integers(1, 30)), int(rng.integers(1, 12)), seed + k, r_range=(10, 128), h_range=(20, 260)) for k in range(int(rng.integers(1, 9)))]
+            got = queue.run_regions(regs)
+            one = ph.compute_regions(regs)
+            ok &= all(np.array_equal(a, b) for a, b in zip(got, one))
+            counts["queue"] += 1
         else:
             os.environ["MGX_SW_PAIRED"] = str(rng.choice(["0", "1"]))
             w = synth.gen_sw_pairs(int(rng.integers(1, 400)), seed, ref_range=(1, int(rng.choice([60, 300, 700, 2048]))), alt_range=(1, int(rng.choice([40, 200, 600]))))
