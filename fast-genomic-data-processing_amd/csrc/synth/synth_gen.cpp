@@ -4,7 +4,9 @@
 // written in C++ so that the 64 M-pair and 200 M-record configurations are generated in seconds.
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -171,6 +173,70 @@ void synth_sortdedup_packed(uint64_t seed, uint64_t n_pair_t, uint64_t n_frag_t,
             out[2 * t] = A; out[2 * t + 1] = B;
         }
     });
+}
+
+
+// SAM text for the packed records of synth_sortdedup_packed (CLI end-to-end runs at scale): one line per record,
+// queryname-grouped, a CIGAR whose soft clip separates the coordinate from the 5' end, random bases and qualities.
+// Appends to the file `path` (the caller wrote the header); returns the bytes written, or -1.
+long long synth_sam_text(const synth_rec* recs, uint64_t n, uint64_t first_index, uint64_t contig_len, int n_contigs, int read_len,
+                         uint64_t seed, const char* path, int threads) {
+    FILE* f = fopen(path, "ab");
+    if (!f) return -1;
+    const uint64_t L = contig_len * (uint64_t)n_contigs;
+    long long total = 0;
+    const uint64_t block = 1u << 20;                     // records per round: bounded memory
+    for (uint64_t b0 = 0; b0 < n; b0 += block) {
+        const uint64_t b1 = std::min(n, b0 + block);
+        const int T = std::max(1, std::min(threads, 64));
+        std::vector<std::string> parts(T);
+        const uint64_t per = (b1 - b0 + T - 1) / T;
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+            std::string& out = parts[t];
+            const uint64_t a = std::min(b1, b0 + t * per), e = std::min(b1, a + per);
+            out.reserve((e - a) * (size_t)(2 * read_len + 120));
+            char tmp[256];
+            for (uint64_t i = a; i < e; ++i) {
+                const synth_rec& r = recs[i];
+                const uint64_t tpl = (first_index + i) / 2;
+                Stream g{seed ^ ((first_index + i) * kStreamMul)};
+                const bool mapped = !(r.flag & 4);
+                const uint64_t coord = r.coord < L ? r.coord : 0;
+                const int tid = (int)(coord / contig_len);
+                const uint64_t pos = coord % contig_len;
+                const bool rev = (r.flag & 16) != 0;
+                uint64_t clip = 0;
+                if (mapped && !rev && r.coord >= r.prime5) clip = std::min<uint64_t>(r.coord - r.prime5, 20);
+                int len = snprintf(tmp, sizeof tmp, "SYN:1:FC:1:%u:%u:%u\t%u\tchr%d\t%llu\t%d\t", (unsigned)((tpl >> 32) & 0xFFFF),
+                                   (unsigned)((tpl >> 16) & 0xFFFF), (unsigned)(tpl & 0xFFFF), (unsigned)r.flag, tid + 1,
+                                   (unsigned long long)(pos + 1), mapped ? 60 : 0);
+                out.append(tmp, (size_t)len);
+                if (!mapped) out.append("*");
+                else if (clip) { len = snprintf(tmp, sizeof tmp, "%lluS%lluM", (unsigned long long)clip, (unsigned long long)(read_len - clip)); out.append(tmp, (size_t)len); }
+                else { len = snprintf(tmp, sizeof tmp, "%dM", read_len); out.append(tmp, (size_t)len); }
+                len = snprintf(tmp, sizeof tmp, "\t=\t%llu\t%d\t", (unsigned long long)(pos + 1), 0);
+                out.append(tmp, (size_t)len);
+                const size_t at = out.size();
+                out.resize(at + 2 * (size_t)read_len + 2);
+                char* p = &out[at];
+                static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+                for (int c = 0; c < read_len; c += 8) {
+                    const uint64_t z = g.next();
+                    for (int k = 0; k < 8 && c + k < read_len; ++k) {
+                        p[c + k] = ACGT[(z >> (8 * k)) & 3];
+                        p[read_len + 1 + c + k] = (char)(33 + 2 + ((z >> (8 * k + 2)) & 63) % 40);
+                    }
+                }
+                p[read_len] = '\t';
+                p[2 * read_len + 1] = '\n';
+            }
+        });
+        for (auto& x : th) x.join();
+        for (auto& s2 : parts) { if (!s2.empty() && fwrite(s2.data(), 1, s2.size(), f) != s2.size()) { fclose(f); return -1; } total += (long long)s2.size(); }
+    }
+    fclose(f);
+    return total;
 }
 
 }  // extern "C"

@@ -1,0 +1,43 @@
+"""End-to-end run of the sortmardup CLI at scale: N synthetic records (BASELINE configs[3] distribution) written as
+SAM text, then `sortmardup -I in.sam -O out.bam` under /usr/bin/time -v; prints the tool's stage timings, the peak
+resident set and the text size.  A second run with a different slice size must give a byte-identical BAM.
+usage: dev_cli_scale.py [n_records] [threads] [dir]"""
+import hashlib, importlib, os, re, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+pkg = importlib.import_module("fast-genomic-data-processing_amd")
+from test_cli_gpu import build_cli
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+d = sys.argv[3] if len(sys.argv) > 3 else "/dev/shm"
+sam, bam = os.path.join(d, "mgx_scale.sam"), os.path.join(d, "mgx_scale.bam")
+t0 = time.time()
+recs, L = pkg.synth.gen_sortdedup_packed_fast(n, 0x5EED0004)
+size = pkg.synth.write_sam_from_packed(sam, recs)
+del recs
+print(f"{n} records, SAM text {size / 1e9:.2f} GB written in {time.time() - t0:.1f} s", flush=True)
+exe = build_cli()
+
+
+def run(extra, tag):
+    t = time.time()
+    res = subprocess.run(["/usr/bin/time", "-v", exe, "-I", sam, "-O", bam, "-t", str(threads)] + extra, capture_output=True, text=True)
+    wall = time.time() - t
+    if res.returncode:
+        print(res.stdout[-2000:], res.stderr[-2000:]); sys.exit(1)
+    rss = int(re.search(r"Maximum resident set size \(kbytes\): (\d+)", res.stderr).group(1)) / 1e6
+    print(f"--- {tag}: wall {wall:.2f} s = {n / wall / 1e6:.2f} Mrecords/s end to end, peak RSS {rss:.2f} GB (text {size / 1e9:.2f} GB)")
+    print(res.stdout.strip(), flush=True)
+    h = hashlib.md5()
+    with open(bam, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest(), os.path.getsize(bam)
+
+
+a = run([], "default slices (32 MB)")
+b = run(["-s", str(8 << 20)], "8 MB slices")
+print("BAM size", a[1], "identical output for both slice sizes:", a == b)
+for p in (sam, bam, bam + ".bai"):
+    if os.path.exists(p):
+        os.remove(p)
