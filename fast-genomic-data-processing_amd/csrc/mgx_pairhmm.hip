@@ -44,6 +44,10 @@ constexpr int kNarrowMaxRPL = 8, kG8MaxRPL = 8, kG16MaxRPL = 12, kG64MinRPL = 4,
 constexpr int kMaxRowsG4 = 4 * kNarrowMaxRPL, kMaxRowsG8 = 8 * kG8MaxRPL;
 constexpr int kMaxRowsG16 = 16 * kG16MaxRPL;
 constexpr int kMaxRowsG64 = 64 * kG64MaxRPL;
+// Longer reads are strip-mined: 64 lanes x 16 rows per strip, the strips sweep the haplotype one after the other
+// (pairhmm_fwd_strip).  The limit below only keeps row indices and the boundary scratch in 32 bits.
+constexpr int kMaxRowsStrip = 1 << 20;
+constexpr int kStripMarkRPL = kG64MaxRPL + 1;      // shape_of's RPL value for the strip-mined class
 constexpr uint32_t kMaxLdsPerBlock = 64 * 1024;
 
 struct Bin {
@@ -54,6 +58,7 @@ struct Bin {
     uint64_t cells = 0, alg_bytes = 0;
     // launch geometry
     uint32_t block = 256, lds_stride = 0, grid_f32 = 0, grid_f64 = 0, grid_f64_all = 0;
+    bool strip = false;              // reads longer than 1024 bases: the strip-mined kernel, one test case per workgroup
 };
 
 }  // namespace
@@ -86,6 +91,7 @@ struct mgx_pairhmm {
     float log10_initial_f = 0; double log10_initial_d = 0;
     int n_cu = 256;
     std::vector<Slab> free_slabs;
+    void* d_strip = nullptr; size_t strip_cap = 0;      // boundary rows of the strip-mined class (one compute stream: launches do not overlap)
 };
 
 struct mgx_pairhmm_batch {
@@ -161,6 +167,7 @@ inline void shape_of(uint32_t R, int* G, int* RPL) {
     else if (R <= g8_rows && min_g <= 8) { *G = 8; *RPL = (int)((R + 7) / 8); }
     else if (R <= (uint32_t)kMaxRowsG16) { *G = 16; *RPL = (int)((R + 15) / 16); }
     else if (R <= (uint32_t)kMaxRowsG64) { *G = 64; *RPL = std::max(kG64MinRPL, (int)((R + 63) / 64)); }
+    else if (R <= (uint32_t)kMaxRowsStrip) { *G = 64; *RPL = kStripMarkRPL; }
     else { *G = 0; *RPL = 0; }
 }
 // dynamic LDS of one block: per-wavefront emission table (fp32 only) + per-group haplotype codes
@@ -171,11 +178,14 @@ inline uint32_t lds_bytes(const Bin& bin, bool f32) {
 }
 // bins in order of (G, RPL): [G=4: 1..8][G=8: 1..8][G=16: 1..12][G=64: 4..16]
 constexpr int kBinG8 = kNarrowMaxRPL, kBinG16 = kBinG8 + kG8MaxRPL, kBinG64 = kBinG16 + kG16MaxRPL;
-constexpr int kBins = kBinG64 + (kG64MaxRPL - kG64MinRPL + 1);
+constexpr int kBinStrip = kBinG64 + (kG64MaxRPL - kG64MinRPL + 1);      // the strip-mined class comes last
+constexpr int kBins = kBinStrip + 1;
 inline int bin_index(int G, int RPL) {
+    if (G == 64 && RPL == kStripMarkRPL) return kBinStrip;
     return G == 4 ? RPL - 1 : G == 8 ? kBinG8 + RPL - 1 : G == 16 ? kBinG16 + RPL - 1 : kBinG64 + RPL - kG64MinRPL;
 }
 inline void bin_shape(int k, Bin* b) {
+    if (k == kBinStrip) { b->G = 64; b->RPL = kG64MaxRPL; b->Gd = 64; b->RPLd = kG64MaxRPL; b->strip = true; return; }
     if (k < kBinG8) { b->G = 4; b->RPL = k + 1; }
     else if (k < kBinG16) { b->G = 8; b->RPL = k - kBinG8 + 1; }
     else if (k < kBinG64) { b->G = 16; b->RPL = k - kBinG16 + 1; }
@@ -199,6 +209,13 @@ int finalize_bin(Bin& bin, int n_cu) {
         set_error("haplotype of %u bases does not fit the LDS staging buffer", bin.max_h);
         return -E2BIG;
     }
+    if (bin.strip) {
+        // one test case per workgroup, a bounded grid walking the job list: the boundary rows between strips live in
+        // a scratch array indexed by workgroup
+        bin.block = 64;
+        bin.grid_f32 = bin.grid_f64 = bin.grid_f64_all = std::min<uint32_t>(bin.job_count, (uint32_t)n_cu * 4u);
+        return 0;
+    }
     const uint32_t gpb = bin.block / bin.G, gpbd = bin.block / bin.Gd;
     bin.grid_f32 = (bin.job_count + gpb - 1) / gpb;
     bin.grid_f64_all = (bin.job_count + gpbd - 1) / gpbd;
@@ -209,7 +226,7 @@ int finalize_bin(Bin& bin, int n_cu) {
 void merge_small_bins(uint64_t (&count)[kBins], int (&remap)[kBins]) {
     for (int k = 0; k < kBins; ++k) remap[k] = k;
     for (int k = 0; k + 1 < kBins; ++k) {
-        if (k + 1 == kBinG8 || k + 1 == kBinG16 || k + 1 == kBinG64) continue;   // never across a group-width boundary
+        if (k + 1 == kBinG8 || k + 1 == kBinG16 || k + 1 == kBinG64 || k + 1 == kBinStrip) continue;   // never across a group-width boundary
         if (count[k] && count[k] < kMergeBelow) { count[k + 1] += count[k]; count[k] = 0; remap[k] = k + 1; }
     }
     for (int k = 0; k < kBins; ++k) { int t = k; while (remap[t] != t) t = remap[t]; remap[k] = t; }
@@ -365,6 +382,7 @@ void mgx_pairhmm_destroy(mgx_pairhmm_t* c) {
     (void)hipFree(c->d_ph2pr_d); (void)hipFree(c->d_mm_d);
     (void)hipFree(c->d_div3_f); (void)hipFree(c->d_ratio_f); (void)hipFree(c->d_div3_d); (void)hipFree(c->d_ratio_d);
     for (auto& sl : c->free_slabs) { (void)hipFree(sl.dev); if (sl.pin) (void)hipHostFree(sl.pin); }
+    (void)hipFree(c->d_strip);
     if (c->compute) (void)hipStreamDestroy(c->compute);
     if (c->copy) (void)hipStreamDestroy(c->copy);
     if (c->d2h) (void)hipStreamDestroy(c->d2h);
@@ -411,7 +429,7 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
         if (R == 0) { set_error("read %llu is empty", (unsigned long long)r); return -EINVAL; }
         int G, RPL;
         shape_of((uint32_t)std::min<uint64_t>(R, 0xFFFFFFFFull), &G, &RPL);
-        if (G == 0) { set_error("read %llu: read of %llu bases exceeds the %d-row limit", (unsigned long long)r, (unsigned long long)R, kMaxRowsG64); return -E2BIG; }
+        if (G == 0) { set_error("read %llu: read of %llu bases exceeds the %d-row limit", (unsigned long long)r, (unsigned long long)R, kMaxRowsStrip); return -E2BIG; }
         rbin[r] = (uint8_t)bin_index(G, RPL);
         count[rbin[r]] += nh;
     }
@@ -564,7 +582,7 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
                 if (Rl == 0) { set_error("region %u: read %llu is empty", g, (unsigned long long)r); return -EINVAL; }
                 int G, RPL;
                 shape_of((uint32_t)std::min<uint64_t>(Rl, 0xFFFFFFFFull), &G, &RPL);
-                if (G == 0) { set_error("region %u: read of %llu bases exceeds the %d-row limit", g, (unsigned long long)Rl, kMaxRowsG64); return -E2BIG; }
+                if (G == 0) { set_error("region %u: read of %llu bases exceeds the %d-row limit", g, (unsigned long long)Rl, kMaxRowsStrip); return -E2BIG; }
                 RInfo& ri = rinfo[r_at + r];
                 ri.off = rb + (in.read_off[r] - in.read_off[0]); ri.len = (uint32_t)Rl; ri.region = g; ri.bin = (uint8_t)bin_index(G, RPL);
                 count[ri.bin] += in.n_haps;
@@ -750,7 +768,7 @@ int create_pairs(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const mgx::Pac
         if (R == 0 || H == 0) { set_error("test case %llu: empty read or haplotype", (unsigned long long)i); return -EINVAL; }
         int G, RPL;
         shape_of((uint32_t)std::min<uint64_t>(R, 0xFFFFFFFFull), &G, &RPL);
-        if (G == 0) { set_error("test case %llu: read of %llu bases exceeds the %d-row limit", (unsigned long long)i, (unsigned long long)R, kMaxRowsG64); return -E2BIG; }
+        if (G == 0) { set_error("test case %llu: read of %llu bases exceeds the %d-row limit", (unsigned long long)i, (unsigned long long)R, kMaxRowsStrip); return -E2BIG; }
         if (H > 0x7FFFFFF0ull) { set_error("haplotype too long"); return -E2BIG; }
         const int bi = bin_index(G, RPL);
         bin_of[i] = (uint32_t)bi;
@@ -934,7 +952,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     base.log10_initial_d = c->log10_initial_d;
     auto launch_f64 = [&](KernelArgs a, int Gd, int RPLd, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t sk) -> int {
         a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d; a.ph2pr_div3 = c->d_div3_d; a.gap_ratio = c->d_ratio_d;
-        KernelFn f = pick_kernel<double>(Gd, RPLd);
+        KernelFn f = a.strip_scratch ? (KernelFn)pairhmm_fwd_strip<double> : pick_kernel<double>(Gd, RPLd);
         if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", Gd, RPLd); return -ENOSYS; }
         hipLaunchKernelGGL(f, dim3(grid), dim3(block), lds, sk, a);
         return 0;
@@ -1006,6 +1024,17 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         hipStream_t sk = (int)(at % (size_t)n_str) == 0 ? s : c->aux[at % (size_t)n_str - 1];
         const bool shared = narrow(bin) && !force_f64 && n_str == 1;
         KernelArgs a = base;
+        if (bin.strip) {
+            a.strip_stride = (bin.max_h + 63u) & ~63u;
+            const size_t need = (size_t)bin.grid_f32 * 6u * a.strip_stride * sizeof(double);
+            if (need > c->strip_cap) {
+                HIP_TRY(hipStreamSynchronize(s));           // an earlier launch may still be using the old array
+                (void)hipFree(c->d_strip); c->d_strip = nullptr; c->strip_cap = 0;
+                HIP_TRY(hipMalloc(&c->d_strip, need));
+                c->strip_cap = need;
+            }
+            a.strip_scratch = c->d_strip;
+        }
         a.rerun_list = shared ? b->d_rerun_list : b->d_rerun_list + bin.job_begin;
         a.rerun_count = b->d_rerun_count + (shared ? kSharedCount : (int)k);
         a.lds_stride = bin.lds_stride;
@@ -1013,7 +1042,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         if (!force_f64 && !in_multi[k]) {
             a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count;
             a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f; a.ph2pr_div3 = c->d_div3_f; a.gap_ratio = c->d_ratio_f;
-            KernelFn f = pick_kernel<float>(bin.G, bin.RPL);
+            KernelFn f = bin.strip ? (KernelFn)pairhmm_fwd_strip<float> : pick_kernel<float>(bin.G, bin.RPL);
             if (!f) { set_error("no fp32 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
             if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 0], sk));
             hipLaunchKernelGGL(f, dim3(bin.grid_f32), dim3(bin.block), lds_bytes(bin, true), sk, a);

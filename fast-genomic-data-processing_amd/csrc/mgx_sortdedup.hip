@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <new>
 #include <thread>
@@ -1368,28 +1369,59 @@ int ensure_staging(mgx_sortdedup_t* c, size_t chunk) {
 
 int upload_threads() {
     // one core moves ~12 GB/s into the staging buffer, less than a quarter of what the link takes: every piece is
-    // split over several threads (MGX_UPLOAD_THREADS; default half the cores, at most 8 -- with 4 the 24-byte
-    // conversion, not the link, bounded the upload: 200 M records in 0.133 s; measured on the GPU box)
+    // split over a gang of threads (MGX_UPLOAD_THREADS, default 4).  Measured on the GPU box, 200 M records, 24-byte
+    // wire form (profiles/r02_upload_threads.txt): 4 threads 89.6 ms, 8: 95.9, 12: 97.4, 16: 113.4 -- beyond four the
+    // threads only compete for memory bandwidth; raw 32-byte records with 8 threads: 114.9 ms.
     static const int n_thr = [] {
         const char* e = getenv("MGX_UPLOAD_THREADS");
-        const int hw = (int)std::thread::hardware_concurrency();
-        const int v = e ? atoi(e) : std::max(2, std::min(8, hw / 2));
+        const int v = e ? atoi(e) : 4;
         return v < 1 ? 1 : (v > 16 ? 16 : v);
     }();
     return n_thr;
 }
 
 extern "C++" {
-template <class F>
-void split_over_threads(size_t n_items, size_t min_per_thread, F body) {      // body(first, last)
-    const int n_thr = upload_threads();
-    if (n_thr == 1 || n_items < 2 * min_per_thread) { body((size_t)0, n_items); return; }
-    std::thread th[16];
-    const size_t part = (n_items + (size_t)n_thr - 1) / (size_t)n_thr;
-    int used = 0;
-    for (size_t o = 0; o < n_items; o += part) th[used++] = std::thread([=] { body(o, std::min(n_items, o + part)); });
-    for (int t = 0; t < used; ++t) th[t].join();
-}
+// A gang of helper threads that lives for one upload: every staging piece (~1 ms of copying) is split over the
+// gang without creating threads per piece (eight std::thread starts cost a quarter of a piece's copy time).
+class Gang {
+public:
+    explicit Gang(int n) : n_(n < 1 ? 1 : n) {
+        for (int t = 1; t < n_; ++t) th_.emplace_back([this, t] { loop(t); });
+    }
+    ~Gang() {
+        stop_.store(true);
+        gen_.fetch_add(1);
+        for (auto& t : th_) t.join();
+    }
+    // body(first, last) over [0, n_items) in n contiguous shares; returns when all shares are done
+    template <class F>
+    void run(size_t n_items, size_t min_per_thread, F body) {
+        if (n_ == 1 || n_items < 2 * min_per_thread) { body((size_t)0, n_items); return; }
+        const size_t part = (n_items + (size_t)n_ - 1) / (size_t)n_;
+        fn_ = [&, part, n_items](int t) { const size_t a = std::min(n_items, (size_t)t * part), b = std::min(n_items, a + part); if (a < b) body(a, b); };
+        done_.store(0);
+        gen_.fetch_add(1);
+        fn_(0);
+        while (done_.load() != n_ - 1) std::this_thread::yield();
+    }
+private:
+    void loop(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            while (gen_.load() == seen) std::this_thread::yield();
+            seen = gen_.load();
+            if (stop_.load()) return;
+            fn_(t);
+            done_.fetch_add(1);
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::function<void(int)> fn_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> done_{0};
+    std::atomic<bool> stop_{false};
+};
 }  // extern "C++"
 
 // host memory -> HBM through two pinned staging buffers on the copy stream (asynchronous; the caller syncs)
@@ -1399,12 +1431,13 @@ int stream_up(mgx_sortdedup_t* c, void* dst, const void* src_, size_t total) {
     if (rc) return rc;
     size_t off = 0;
     int buf = 0;
+    Gang gang(total >= (32u << 20) ? upload_threads() : 1);
     while (off < total) {
         const size_t len = std::min(c->pinned_cap, total - off);
         HIP_TRY(hipEventSynchronize(c->pin_ev[buf]));
         const char* src = reinterpret_cast<const char*>(src_) + off;
         char* stage = static_cast<char*>(c->pinned[buf]);
-        split_over_threads(len, 4u << 20, [=](size_t a, size_t b) { memcpy(stage + a, src + a, b - a); });
+        gang.run(len, 4u << 20, [=](size_t a, size_t b) { memcpy(stage + a, src + a, b - a); });
         HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(dst) + off, c->pinned[buf], len, hipMemcpyHostToDevice, c->copy));
         HIP_TRY(hipEventRecord(c->pin_ev[buf], c->copy));
         off += len; buf ^= 1;
@@ -1421,6 +1454,7 @@ int stream_up_recs(mgx_sortdedup_t* c, uint64_t first, uint64_t n, const mgx_rec
     if (rc) return rc;
     const size_t piece = c->pinned_cap / sizeof(mgx_rec_t);
     int buf = 0;
+    Gang gang(total >= (32u << 20) ? upload_threads() : 1);
     for (uint64_t off = 0; off < n; off += piece, buf ^= 1) {
         const size_t m = (size_t)std::min<uint64_t>(piece, n - off);
         HIP_TRY(hipEventSynchronize(c->pin_ev[buf]));
@@ -1434,7 +1468,7 @@ int stream_up_recs(mgx_sortdedup_t* c, uint64_t first, uint64_t n, const mgx_rec
             const uint64_t* s64 = reinterpret_cast<const uint64_t*>(src);
             static_assert(sizeof(mgx_rec_t) == 32 && offsetof(mgx_rec_t, prime5) == 8 && offsetof(mgx_rec_t, mate) == 16, "record layout");
             std::atomic<uint64_t> high{0};
-            split_over_threads(m, 65536, [&, w, s64](size_t a, size_t b) {
+            gang.run(m, 65536, [&, w, s64](size_t a, size_t b) {
                 uint64_t hi = 0;
                 for (size_t i = a; i < b; ++i) {
                     const uint64_t c0 = s64[4 * i], p0 = s64[4 * i + 1];
@@ -1453,7 +1487,7 @@ int stream_up_recs(mgx_sortdedup_t* c, uint64_t first, uint64_t n, const mgx_rec
         } else {
             char* stage = static_cast<char*>(c->pinned[buf]);
             const char* s8 = reinterpret_cast<const char*>(src);
-            split_over_threads(m * sizeof(mgx_rec_t), 4u << 20, [=](size_t a, size_t b) { memcpy(stage + a, s8 + a, b - a); });
+            gang.run(m * sizeof(mgx_rec_t), 4u << 20, [=](size_t a, size_t b) { memcpy(stage + a, s8 + a, b - a); });
             HIP_TRY(hipMemcpyAsync(dst, c->pinned[buf], m * sizeof(mgx_rec_t), hipMemcpyHostToDevice, c->copy));
         }
         HIP_TRY(hipEventRecord(c->pin_ev[buf], c->copy));

@@ -23,7 +23,9 @@
  * (haplotypecaller/ReadForPairHMM.cpp:18-38): bases, base quals, insertion GOP, deletion GOP,
  * gap-continuation penalty.  Every quality byte is masked with 127 on the device exactly as the
  * reference does; bases are ASCII, any byte other than A/C/G/T/N is treated as 'A'
- * (pairhmm_common.h:75-81).
+ * (pairhmm_common.h:75-81).  Reads may be up to 2^20 bases long (beyond 1024 a strip-mined kernel is used; the
+ * whole-region call mgx_pairhmm_region(s) takes reads up to 1024 bases), haplotypes up to about 40 000 bases;
+ * longer sequences are rejected with -E2BIG.
  *
  * All functions return 0 on success or a negative errno-style code; no exception crosses the
  * boundary.  mgx_last_error() returns a thread-local message for the last failure.

@@ -99,7 +99,9 @@ def test_full_size_properties(engine, oracle, synth):
 
 
 def test_read_longer_than_supported_is_an_error_not_a_fallback(pkg, engine, synth):
-    d = synth.gen_pairhmm_pairs(4, 3, r_range=(1025, 1025), h_range=(1100, 1100))
+    """Reads up to 2^20 bases are computed (the strip-mined class, test_reads_longer_than_one_strip); beyond that the
+    call fails with -E2BIG instead of falling back to anything."""
+    d = synth.gen_pairhmm_pairs(1, 3, r_range=((1 << 20) + 1, (1 << 20) + 1), h_range=(10, 10))
     with pytest.raises(pkg.MgxError, match="row limit"):
         engine.compute(d)
 
@@ -236,3 +238,35 @@ def test_region_batch_with_empty_and_many_regions(engine, synth):
     for k in (0, 1, 499, 501, 777, 1000):
         d = dict(regs[k]); d["pair_read"] = None; d["pair_hap"] = None
         assert np.array_equal(got[k], engine.compute(d).reshape(got[k].shape))
+
+
+@pytest.mark.parametrize("r_range,h_range,n,gcp", [((1025, 1100), (900, 1300), 40, 10), ((2049, 3300), (50, 700), 40, 10),
+                                                    ((1025, 2500), (1000, 2600), 24, 0), ((1024, 1026), (1, 40), 30, 10)])
+def test_reads_longer_than_one_strip(pkg, engine, oracle, synth, r_range, h_range, n, gcp):
+    """Reads of more than 1024 bases take the strip-mined class (64 x 16 rows per strip, boundary rows through
+    global memory), in fp32 and in the fp64 re-run; gap-continuation byte 0 forces the plain 8-operation form.
+    The reference handles any read length."""
+    d = synth.gen_pairhmm_pairs(n, 77 + n, r_range=r_range, h_range=h_range, gcp=gcp, random_read_rate=0.1)
+    want, wused = oracle.batch(d)
+    out, used, st = run(engine, d)
+    assert_log10_close(out, want)
+    assert (used != wused).sum() <= 2
+    assert st["n_rerun_f64"] == int(used.sum()) and st["cells"] == d["cells"]
+    # forced double precision and the queue take the same class
+    eng64 = pkg.PairHMMEngine(0, flags=pkg.pairhmm.FORCE_DOUBLE)
+    out64, used64, _ = run(eng64, d)
+    eng64.close()
+    assert used64.all()
+    assert_log10_close(out64, want)
+    q = pkg.PairHMMQueue(devices=(0,), lanes_per_device=2, batch_pairs=7)
+    assert np.array_equal(q.run(d), out)
+    q.close()
+
+
+def test_long_and_short_reads_in_one_region(engine, oracle, synth):
+    """A cross-product batch whose reads span every class, including the strip-mined one."""
+    d = synth.gen_pairhmm_region(24, 7, 5, r_range=(20, 2600), h_range=(300, 900))
+    want, _ = oracle.batch(d)
+    got = engine.compute(dict(d, pair_read=None, pair_hap=None))
+    assert_log10_close(got, want)
+    assert np.array_equal(engine.compute_regions([d])[0].ravel(), got)
