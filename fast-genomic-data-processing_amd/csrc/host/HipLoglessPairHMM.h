@@ -110,6 +110,20 @@ public:
         queue_.clear();
     }
 
+    // The same through a host work queue shared by the worker threads (mgx_pairhmm_queue_*, BASELINE configs[2]): the
+    // parked regions are cut into batches that the queue's lanes -- possibly on several GPUs -- pull, pack and upload
+    // while earlier batches compute.  Values are identical to flush().
+    void flush(mgx_pairhmm_queue_t* queue) {
+        if (queue_.empty()) return;
+        std::vector<mgx_pairhmm_input_t> ins;
+        std::vector<double*> outs;
+        for (auto& p : queue_) { ins.push_back(p.input()); outs.push_back(p.out.data()); }
+        const int rc = mgx_pairhmm_queue_run_regions(queue, (uint32_t)ins.size(), ins.data(), outs.data());
+        if (rc != 0) { queue_.clear(); throw std::runtime_error(std::string("mgx_pairhmm_queue_run_regions: ") + mgx_last_error()); }
+        for (auto& p : queue_) scatter(p);
+        queue_.clear();
+    }
+
     // the reference calls the _trie variants only when is_use_trietree_optimize is true; they are
     // provided so the virtual interface is complete and return the same values
     void computeLog10Likelihoods_trie(Matrix* m, std::vector<std::shared_ptr<Read>>& r, GcpMap* g) { computeLog10Likelihoods(m, r, g); }

@@ -66,7 +66,8 @@ int main(int argc, char** argv) {
     hmm.initialize(haps, per_sample, 0, 0);
     MockMatrix m; m.n_reads = n_reads; m.v.assign((size_t)n_haps * n_reads, 0.0);
     for (int h = n_haps - 1; h >= 0; --h) m.order.push_back(haps[h]);      // reversed allele order on purpose
-    if (argc > 2 && std::string(argv[2]) == "queue") {
+    const std::string mode = argc > 2 ? argv[2] : "";
+    if (mode == "queue" || mode == "workqueue") {
         // row F1: the same reads as three "regions" (same haplotypes) parked and sent as one batch
         std::vector<std::vector<std::shared_ptr<MockRead>>> parts(3);
         for (int r = 0; r < n_reads; ++r) parts[r % 3].push_back(reads[r]);
@@ -76,7 +77,16 @@ int main(int argc, char** argv) {
             hmm.enqueue(&ms[k], parts[k], &gcp);
         }
         if (hmm.queued() != 3) return 3;
-        hmm.flush();
+        if (mode == "workqueue") {        // through the host work queue (two lanes, batches of about 100 test cases)
+            mgx_pairhmm_queue_config_t cfg{};
+            cfg.lanes_per_device = 2; cfg.batch_pairs = 100;
+            mgx_pairhmm_queue_t* q = nullptr;
+            if (mgx_pairhmm_queue_create(&cfg, &q)) return 4;
+            hmm.flush(q);
+            mgx_pairhmm_queue_destroy(q);
+        } else {
+            hmm.flush();
+        }
         for (int r = 0; r < n_reads; ++r)
             for (int a = 0; a < n_haps; ++a) m.v[(size_t)a * n_reads + r] = ms[r % 3].v[(size_t)a * ms[r % 3].n_reads + r / 3];
     } else {

@@ -55,6 +55,10 @@ def test_adapter_matches_oracle(tmp_path, oracle, synth):
     out_q = subprocess.check_output([build_adapter(), str(path), "queue"], text=True)
     got_q = np.array([[float(x) for x in line.split()] for line in out_q.strip().splitlines()])
     assert np.array_equal(got_q, got)
+    # ... and through the host work queue (flush(queue)): identical again
+    out_w = subprocess.check_output([build_adapter(), str(path), "workqueue"], text=True)
+    got_w = np.array([[float(x) for x in line.split()] for line in out_w.strip().splitlines()])
+    assert np.array_equal(got_w, got)
     # duplicated reads must come out bit-identical (they are computed once)
     for k in range(6):
         src, dst = k % (n_reads - 6), n_reads - 6 + k
