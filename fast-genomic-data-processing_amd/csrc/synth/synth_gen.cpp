@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -179,9 +180,10 @@ void synth_sortdedup_packed(uint64_t seed, uint64_t n_pair_t, uint64_t n_frag_t,
 // SAM text for the packed records of synth_sortdedup_packed (CLI end-to-end runs at scale): one line per record,
 // queryname-grouped, a CIGAR whose soft clip separates the coordinate from the 5' end, random bases and qualities.
 // Appends to the file `path` (the caller wrote the header); returns the bytes written, or -1.
+// (fd >= 0: written to that descriptor instead -- a pipe into the tool's stdin -- and `path` is ignored)
 long long synth_sam_text(const synth_rec* recs, uint64_t n, uint64_t first_index, uint64_t contig_len, int n_contigs, int read_len,
-                         uint64_t seed, const char* path, int threads) {
-    FILE* f = fopen(path, "ab");
+                         uint64_t seed, const char* path, int threads, int fd) {
+    FILE* f = fd >= 0 ? fdopen(dup(fd), "ab") : fopen(path, "ab");
     if (!f) return -1;
     const uint64_t L = contig_len * (uint64_t)n_contigs;
     long long total = 0;

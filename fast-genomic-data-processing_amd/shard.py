@@ -1,12 +1,13 @@
 """Multi-GPU sharding of the two hot paths: one process per GPU, NO collective on the data path.
 
-PairHMM test cases are independent and sort/mark-duplicate shards are coordinate ranges routed by
-the host, so a rank only ever needs to know which slice is its own.
+PairHMM test cases are independent, so rank r owns ``shard_bounds(total, r, world)`` of ONE stream (its resident
+batch and the range it gives its host work queue, ``PairHMMQueue.run(lo, hi)``); sort / mark-duplicate shards are
+coordinate ranges cut by the host router (``sortdedup.Routed``, mgx_sortdedup_route) with ``only_shard = rank``
+(SURVEY.md section 8e).
 ``torch.distributed`` is used for exactly two things: the barrier around the timed region and the
 max-over-ranks of its duration (the bench contract)."""
 import os
 
-import numpy as np
 
 
 def env_rank():
@@ -19,24 +20,6 @@ def shard_bounds(n_items, rank, world):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
-
-
-def shard_pairs(d, rank, world):
-    """Slice of a packed PairHMM batch: the rank's share of the test-case list (reads and
-    haplotypes stay shared and are only referenced by index)."""
-    lo, hi = shard_bounds(len(d["pair_read"]), rank, world)
-    out = dict(d)
-    out["pair_read"] = np.ascontiguousarray(d["pair_read"][lo:hi])
-    out["pair_hap"] = np.ascontiguousarray(d["pair_hap"][lo:hi])
-    return out, (lo, hi)
-
-
-def coordinate_shards(coord, L, world):
-    """Host routing step of the sort/mark-duplicate path: rank k owns unified coordinates
-    [k*ceil(L/world), (k+1)*ceil(L/world)) -- what the reference's 100 range partitions do
-    (sortmardup/tbb/range_partitioner.h:98-100).  Returns the owning rank of every key."""
-    width = (L + world) // world
-    return np.minimum(coord // np.uint64(width), np.uint64(world - 1)).astype(np.int64)
 
 
 def max_over_ranks(value, dist=None, device=None):

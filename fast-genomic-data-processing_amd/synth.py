@@ -428,26 +428,29 @@ def gen_sortdedup_packed_fast(n_records, seed, n_contigs=25, contig_len=124_000_
     return (rec[:n_records] if 2 * n_t >= n_records else rec), L
 
 
-def write_sam_from_packed(path, recs, n_contigs=25, contig_len=124_000_000, read_len=150, seed=1, threads=0):
+def write_sam_from_packed(path, recs, n_contigs=25, contig_len=124_000_000, read_len=150, seed=1, threads=0, fileobj=None):
     """SAM text (header + one line per packed record, queryname-grouped) for CLI runs at scale, written by the
-    threaded C++ generator.  Returns the bytes written."""
+    threaded C++ generator to ``path``, or to the open binary ``fileobj`` (e.g. the stdin pipe of the tool).
+    Returns the bytes written."""
     import ctypes as C
     import os
     lib = _synth_lib()
     lib.synth_sam_text.restype = C.c_longlong
     threads = threads or min(len(os.sched_getaffinity(0)), 32)
     recs = np.ascontiguousarray(recs)
-    with open(path, "w") as f:
-        f.write("@HD\tVN:1.6\tSO:queryname\n")
-        for k in range(n_contigs):
-            f.write(f"@SQ\tSN:chr{k + 1}\tLN:{contig_len}\n")
-        f.write("@PG\tID:synth\tPN:synth\n")
-    hdr = os.path.getsize(path)
+    header = "@HD\tVN:1.6\tSO:queryname\n" + "".join(f"@SQ\tSN:chr{k + 1}\tLN:{contig_len}\n" for k in range(n_contigs)) + "@PG\tID:synth\tPN:synth\n"
+    if fileobj is not None:
+        fileobj.write(header.encode()); fileobj.flush()
+        fd = fileobj.fileno()
+    else:
+        with open(path, "w") as f:
+            f.write(header)
+        fd = -1
     n = lib.synth_sam_text(recs.ctypes.data_as(C.c_void_p), C.c_uint64(len(recs)), C.c_uint64(0), C.c_uint64(contig_len), C.c_int(n_contigs),
-                           C.c_int(read_len), C.c_uint64(seed), path.encode(), C.c_int(threads))
+                           C.c_int(read_len), C.c_uint64(seed), (path or "").encode(), C.c_int(threads), C.c_int(fd))
     if n < 0:
         raise OSError(f"cannot write {path}")
-    return hdr + n
+    return len(header) + n
 
 
 def raw_from_packed(recs, n_contigs=25, contig_len=124_000_000, read_len=150, seed=1):

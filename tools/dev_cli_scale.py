@@ -38,6 +38,21 @@ def run(extra, tag):
 a = run([], "default slices (32 MB)")
 b = run(["-s", str(8 << 20)], "8 MB slices")
 print("BAM size", a[1], "identical output for both slice sizes:", a == b)
+if len(sys.argv) > 4:
+    # the same tool fed through stdin by the generator (no text file at all): argv[4] records
+    n2 = int(sys.argv[4])
+    os.remove(sam)
+    recs, L = pkg.synth.gen_sortdedup_packed_fast(n2, 0x5EED0004)
+    t = time.time()
+    p = subprocess.Popen([exe, "-O", bam, "-t", str(threads)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    size2 = pkg.synth.write_sam_from_packed(None, recs, fileobj=p.stdin, threads=max(2, threads // 2))
+    p.stdin.close()
+    out, err = p.stdout.read().decode(), p.stderr.read().decode()
+    rc = p.wait()
+    wall = time.time() - t
+    rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6
+    print(f"--- stdin pipe, {n2} records, {size2 / 1e9:.2f} GB of text never stored: rc {rc}, wall {wall:.2f} s = {n2 / wall / 1e6:.2f} Mrecords/s, peak RSS {rss:.2f} GB, BAM {os.path.getsize(bam) / 1e9:.2f} GB")
+    print(out.strip(), err.strip()[-500:], flush=True)
 for p in (sam, bam, bam + ".bai"):
     if os.path.exists(p):
         os.remove(p)
