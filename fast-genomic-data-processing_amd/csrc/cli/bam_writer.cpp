@@ -6,7 +6,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -20,18 +22,32 @@ constexpr size_t kBgzfHeader = 18, kBgzfFooter = 8;
 template <typename T>
 inline void put(std::vector<uint8_t>& a, T v) { const uint8_t* p = (const uint8_t*)&v; a.insert(a.end(), p, p + sizeof(T)); }
 
-// one BGZF block for in[0, n); appended to out.  level 0..9
-bool bgzf_block(const uint8_t* in, size_t n, int level, std::vector<uint8_t>* out) {
-    uint8_t buf[65536];
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        z_stream zs;
+// A deflate state that is set up once per writer thread and reset per block (deflateInit2 allocates and clears
+// ~256 KB every time; a slice holds thousands of blocks).
+struct Deflater {
+    z_stream zs; bool ok = false; int level;
+    explicit Deflater(int lvl) : level(lvl) {
         memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, attempt == 0 ? level : 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        ok = deflateInit2(&zs, lvl, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+    }
+    ~Deflater() { if (ok) deflateEnd(&zs); }
+    Deflater(const Deflater&) = delete;
+    Deflater& operator=(const Deflater&) = delete;
+};
+
+// one BGZF block for in[0, n); appended to out.  level 0..9
+bool bgzf_block(const uint8_t* in, size_t n, Deflater* df, std::vector<uint8_t>* out) {
+    uint8_t buf[65536];
+    if (!df->ok) return false;
+    std::unique_ptr<Deflater> stored;           // level 0, only when the block does not fit compressed (incompressible data)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt == 1) { stored.reset(new Deflater(0)); if (!stored->ok) return false; }
+        z_stream& zs = attempt == 0 ? df->zs : stored->zs;
+        if (attempt == 0 && deflateReset(&zs) != Z_OK) return false;
         zs.next_in = const_cast<uint8_t*>(in); zs.avail_in = (uInt)n;
         zs.next_out = buf + kBgzfHeader; zs.avail_out = (uInt)(sizeof buf - kBgzfHeader - kBgzfFooter);
         const int rc = deflate(&zs, Z_FINISH);
         const size_t clen = zs.total_out;
-        deflateEnd(&zs);
         if (rc != Z_STREAM_END) continue;      // did not fit: retry stored (always fits for n <= 0xff00)
         const size_t total = kBgzfHeader + clen + kBgzfFooter;
         static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
@@ -53,13 +69,13 @@ struct Slice {                       // output of one writer thread
     bool ok = true;
 };
 
-void compress_slice(const std::vector<RecordRef>& recs, size_t lo, size_t hi, int level, Slice* s) {
+void compress_slice(const std::vector<RecordRef>& recs, size_t lo, size_t hi, Deflater* df, Slice* s) {
     std::vector<uint8_t> block;
     block.reserve(kBlockIn + 1024);
     s->vbeg.resize(hi - lo); s->vend.resize(hi - lo);
     auto flush = [&]() {
         if (block.empty()) return;
-        if (!bgzf_block(block.data(), block.size(), level, &s->bytes)) s->ok = false;
+        if (!bgzf_block(block.data(), block.size(), df, &s->bytes)) s->ok = false;
         block.clear();
     };
     for (size_t k = lo; k < hi; ++k) {
@@ -141,8 +157,11 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
         put<int32_t>(head, (int32_t)hdr.ref_len[i]);
     }
     std::vector<uint8_t> file;
-    for (size_t off = 0; off < head.size(); off += kBlockIn)
-        if (!bgzf_block(head.data() + off, std::min(kBlockIn, head.size() - off), level, &file)) { *err = "deflate failed"; return false; }
+    {
+        Deflater df(level);
+        for (size_t off = 0; off < head.size(); off += kBlockIn)
+            if (!bgzf_block(head.data() + off, std::min(kBlockIn, head.size() - off), &df, &file)) { *err = "deflate failed"; return false; }
+    }
     const uint64_t header_end = file.size();
 
     // ---- records: contiguous slices compressed independently (sortmardup/main.cpp:371-421)
@@ -152,30 +171,48 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
     std::vector<Slice> slices(n_slices);
     std::vector<size_t> lo(n_slices + 1, 0);
     for (size_t s = 0; s <= n_slices; ++s) lo[s] = n_slices ? n * s / n_slices : 0;
+    // the file is written while the slices are still being compressed: the calling thread writes slice s as soon as it
+    // is done (and drops its bytes), the pool compresses ahead
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { *err = "cannot open " + path; return false; }
+    bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+    std::vector<uint64_t> base(n_slices + 1, header_end);
     {
         std::vector<std::thread> pool;
         size_t next = 0;
-        std::mutex* mu = new std::mutex;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<char> done(n_slices, 0);
         for (int t = 0; t < T; ++t)
-            pool.emplace_back([&, mu]() {
+            pool.emplace_back([&]() {
+                Deflater df(level);
                 for (;;) {
                     size_t s;
-                    { std::lock_guard<std::mutex> g(*mu); if (next >= n_slices) return; s = next++; }
-                    compress_slice(recs, lo[s], lo[s + 1], level, &slices[s]);
+                    { std::lock_guard<std::mutex> g(mu); if (next >= n_slices) return; s = next++; }
+                    compress_slice(recs, lo[s], lo[s + 1], &df, &slices[s]);
+                    { std::lock_guard<std::mutex> g(mu); done[s] = 1; }
+                    cv.notify_all();
                 }
             });
+        for (size_t s = 0; s < n_slices; ++s) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[s] != 0; }); }
+            base[s + 1] = base[s] + slices[s].bytes.size();
+            if (ok && slices[s].ok) ok = fwrite(slices[s].bytes.data(), 1, slices[s].bytes.size(), f) == slices[s].bytes.size();
+            std::vector<uint8_t>().swap(slices[s].bytes);
+        }
         for (auto& th : pool) th.join();
-        delete mu;
     }
-    std::vector<uint64_t> base(n_slices + 1, header_end);
-    for (size_t s = 0; s < n_slices; ++s) {
-        if (!slices[s].ok) { *err = "deflate failed"; return false; }
-        base[s + 1] = base[s] + slices[s].bytes.size();
-    }
+    for (size_t s = 0; s < n_slices; ++s)
+        if (!slices[s].ok) { fclose(f); *err = "deflate failed"; return false; }
+    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_block, 1, 28, f) == 28;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { *err = "short write to " + path; return false; }
 
     // ---- BAI (merge of the per-slice offsets, the job of the reference's merge_index)
     std::vector<RefIndex> idx(hdr.ref_name.size());
     uint64_t n_no_coor = 0;
+    int32_t last_tid = -2; uint32_t last_bin = 0; std::vector<std::pair<uint64_t, uint64_t>>* last_chunks = nullptr;
     for (size_t s = 0; s < n_slices; ++s)
         for (size_t k = lo[s]; k < lo[s + 1]; ++k) {
             const RecordRef& r = recs[k];
@@ -183,7 +220,10 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
             if (r.tid < 0 || (size_t)r.tid >= idx.size()) { ++n_no_coor; continue; }
             RefIndex& ri = idx[r.tid];
             const int64_t beg = std::max<int64_t>(r.beg, 0), end = std::max<int64_t>(r.end, beg + 1);
-            auto& chunks = ri.bins[(uint32_t)reg2bin(beg, end)];
+            // the records are coordinate-sorted: neighbours almost always share their bin, so the map is asked once per run
+            const uint32_t bin = (uint32_t)reg2bin(beg, end);
+            if (r.tid != last_tid || bin != last_bin) { last_chunks = &ri.bins[bin]; last_tid = r.tid; last_bin = bin; }
+            auto& chunks = *last_chunks;
             if (!chunks.empty() && chunks.back().second == vb) chunks.back().second = ve;   // contiguous: extend
             else chunks.emplace_back(vb, ve);
             const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
@@ -216,15 +256,7 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
     }
     put<uint64_t>(bai, n_no_coor);
 
-    // ---- write both files
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) { *err = "cannot open " + path; return false; }
-    bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
-    for (size_t s = 0; ok && s < n_slices; ++s) ok = fwrite(slices[s].bytes.data(), 1, slices[s].bytes.size(), f) == slices[s].bytes.size();
-    static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    ok = ok && fwrite(eof_block, 1, 28, f) == 28;
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) { *err = "short write to " + path; return false; }
+    // ---- the index file
     f = fopen((path + ".bai").c_str(), "wb");
     if (!f) { *err = "cannot open " + path + ".bai"; return false; }
     ok = fwrite(bai.data(), 1, bai.size(), f) == bai.size();

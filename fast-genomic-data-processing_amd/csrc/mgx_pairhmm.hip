@@ -346,9 +346,9 @@ int mgx_pairhmm_create(int device, unsigned flags, mgx_pairhmm_t** out) {
     {
         const unsigned pat = (flags >> 8) & 0xFFu;
         const char* e = getenv("MGX_PAIRHMM_STREAMS");
-        // default 1: measured on an MI355X (profiles/r02_pairhmm_shapes.txt) concurrent class kernels on several
-        // streams were SLOWER than one after the other (ragged 1 M test cases: 4163 vs 4227 GCUPS, reads of 33-64
-        // bases 3764 vs 4371) -- the launches compete for the same CUs instead of filling each other's drain
+        // default 1: measured on an MI355X (profiles/r02_pairhmm_streams_ab.txt) two streams gain 2 % on resident ragged
+        // batches (4529 -> 4610 GCUPS) but lose 20 % for region batches through a 4-lane queue (3089 -> 2431: lanes x
+        // streams oversubscribe the device); three and four streams lose everywhere (ragged 3865 / 3895)
         c->n_streams = e ? std::max(1, std::min(1 + mgx_pairhmm::kAux, atoi(e))) : 1;
         if (pat != 0 && pat != 0xFFu) c->n_streams = 1;          // a CU-masked context keeps to its masked stream
         for (int a = 0; a + 1 < c->n_streams; ++a) {
@@ -971,7 +971,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     std::vector<char> in_multi(b->bins.size(), 0);
     b->acct_cells.assign(b->bins.size(), 0); b->acct_bytes.assign(b->bins.size(), 0); b->acct_multi.assign(b->bins.size(), 0);
     for (size_t k = 0; k < b->bins.size(); ++k) { b->acct_cells[k] = b->bins[k].cells; b->acct_bytes[k] = b->bins[k].alg_bytes; }
-    if (multi_ok && !force_f64 && n_str == 1) {
+    if (multi_ok && !force_f64) {
         for (int gset = 0; gset < 2; ++gset) {
             std::vector<size_t> set;
             for (size_t k = 0; k < b->bins.size(); ++k) {
@@ -1022,7 +1022,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         const size_t k = order[at];
         const Bin& bin = b->bins[k];
         hipStream_t sk = (int)(at % (size_t)n_str) == 0 ? s : c->aux[at % (size_t)n_str - 1];
-        const bool shared = narrow(bin) && !force_f64 && n_str == 1;
+        const bool shared = narrow(bin) && !force_f64;
         KernelArgs a = base;
         if (bin.strip) {
             a.strip_stride = (bin.max_h + 63u) & ~63u;
@@ -1058,7 +1058,11 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         }
         if (timing && !books_shared) HIP_TRY(hipEventRecord(ev[4 * k + 3], sk));
     }
-    if (n_narrow_jobs && !force_f64 && n_str == 1) {
+    for (int q = 0; q + 1 < n_str; ++q) {          // the side streams join the compute stream
+        HIP_TRY(hipEventRecord(c->ev_join[q], c->aux[q]));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_join[q], 0));
+    }
+    if (n_narrow_jobs && !force_f64) {
         KernelArgs a = base;
         a.job_list = b->d_rerun_list; a.n_dyn = b->d_rerun_count + kSharedCount; a.n_static = 0; a.job_first = 0;
         a.lds_stride = (narrow_max_h + 2u * 16u + 8u + 15u) & ~15u;
@@ -1068,10 +1072,6 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         const int rc = launch_f64(a, 16, RPLd, grid, 64, 4u * a.lds_stride, s);
         if (rc) return rc;
         if (timing) HIP_TRY(hipEventRecord(ev[4 * first_narrow + 3], s));
-    }
-    for (int q = 0; q + 1 < n_str; ++q) {
-        HIP_TRY(hipEventRecord(c->ev_join[q], c->aux[q]));
-        HIP_TRY(hipStreamWaitEvent(s, c->ev_join[q], 0));
     }
     if (b->has_model && b->d_row_off)
         hipLaunchKernelGGL(pairhmm_normalize_filter_rows, dim3((b->n_reads + 3) / 4), dim3(256), 0, s, b->d_out, b->d_read_len,
