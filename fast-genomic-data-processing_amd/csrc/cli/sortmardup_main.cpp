@@ -7,7 +7,7 @@
 //
 // Ingest is a pipeline over bounded slices of the text, the shape of the reference's reader thread feeding its
 // shuffle threads through a bounded queue of line blocks (main.cpp:505-562, 129-192):
-//   reader (main thread)   reads ~32 MB at a time, cuts at a template boundary (a queryname group never
+//   reader (main thread)   reads ~8 MB at a time, cuts at a template boundary (a queryname group never
 //                          straddles two slices, so mates are found inside their slice), queues the slice;
 //                          the queue is bounded, so at most 2 x threads slices of text are alive
 //   parsers (-t threads)   parse a slice into BAM-ready records and run mgx_sortdedup_pack on it (host keys,
@@ -18,6 +18,7 @@
 //                          still being parsed; only the BAM bytes and 24 bytes of bookkeeping per record stay
 // then mgx_sortdedup_run (MI355X: radix sorts + duplicate search) and BGZF/BAM/BAI output (threads).
 // There is no CPU fallback: without a HIP device the tool exits with an error.
+#include <fcntl.h>
 #include <getopt.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -132,7 +133,7 @@ int main(int argc, char** argv) {
     const char* in_path = nullptr; const char* out_path = nullptr;
     int threads = (int)std::thread::hardware_concurrency();
     int device = 0, level = 6;
-    size_t slice_bytes = 32u << 20;
+    size_t slice_bytes = 8u << 20;     // 8 MB: 20 M records parse in 1.2 s (32 MB slices: 2.1 s -- fewer, longer tasks per thread)
     int c;
     while ((c = getopt(argc, argv, "I:O:t:d:l:s:")) >= 0) {
         switch (c) {
@@ -156,6 +157,10 @@ int main(int argc, char** argv) {
     if (!f) { fprintf(stderr, "cannot read %s\n", in_path ? in_path : "stdin"); return 1; }
     uint64_t file_bytes = 0;
     { struct stat sb; if (in_path && stat(in_path, &sb) == 0) file_bytes = (uint64_t)sb.st_size; }
+#ifdef F_SETPIPE_SZ
+    (void)fcntl(fileno(f), F_SETPIPE_SZ, 1 << 20);          // a pipe on stdin: 1 MB instead of 64 KB per hand-over (ignored for files)
+#endif
+    setvbuf(f, nullptr, _IONBF, 0);                          // read_more() asks for megabytes at a time: no second buffer
 
     // ---- header: read until a line that does not start with '@' is complete
     std::string carry;                                       // text read but not yet handed to a parser

@@ -13,9 +13,35 @@
 #include <cstring>
 #include <vector>
 
+#include <cerrno>
+
 #include "../../include/mgx_pairhmm.h"
+#include "mgx_common.h"
 
 namespace mgx {
+
+// argument checks shared by every entry point that takes an mgx_pairhmm_input_t
+inline int validate(const mgx_pairhmm_input_t* in) {
+    if (!in) { set_error("input is NULL"); return -EINVAL; }
+    if (in->n_pairs == 0 && (in->pair_read || in->n_reads == 0 || in->n_haps == 0)) return 0;
+    if (!in->read_off || !in->hap_off || !in->bases || !in->qual || !in->ins || !in->del ||
+        !in->gcp || !in->hap_bases || (!in->pair_read != !in->pair_hap)) {
+        set_error("a required input array is NULL");
+        return -EINVAL;
+    }
+    if (!in->pair_read && (in->n_reads == 0 || in->n_haps == 0)) {
+        set_error("%llu test cases without pair arrays and without reads or haplotypes", (unsigned long long)in->n_pairs);
+        return -EINVAL;
+    }
+    if (in->n_pairs > 0xFFFFFFF0ull) { set_error("more than 2^32 test cases in one batch"); return -E2BIG; }
+    // offsets index device memory: a decreasing table would turn into an out-of-bounds access there
+    for (uint64_t r = 0; r < in->n_reads; ++r)
+        if (in->read_off[r + 1] < in->read_off[r]) { set_error("read_off is not monotonic at %llu", (unsigned long long)r); return -EINVAL; }
+    for (uint64_t h = 0; h < in->n_haps; ++h)
+        if (in->hap_off[h + 1] < in->hap_off[h]) { set_error("hap_off is not monotonic at %llu", (unsigned long long)h); return -EINVAL; }
+    return 0;
+}
+
 
 struct PackPlan {
     uint64_t lo = 0, hi = 0;

@@ -1,0 +1,83 @@
+// tests/cpp/test_host_sanitize.cpp -- the host-only pieces of the library (record packing, the multi-GPU router and
+// merge, the PairHMM batch packer) driven over seeded random inputs; built by tests/test_host_sanitizers.py with
+// -fsanitize=address,undefined and with -fsanitize=thread (no HIP, no device).  Exit code 0 = nothing reported.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mgx_pairhmm.h"
+#include "mgx_sortdedup.h"
+#include "../../fast-genomic-data-processing_amd/csrc/pairhmm_pack.h"
+
+static uint64_t rng_state = 0x5EED;
+static uint64_t rnd() { rng_state += 0x9E3779B97F4A7C15ull; uint64_t z = rng_state; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+static int route_case(uint64_t n_templates, uint32_t n_shards, uint64_t L) {
+    std::vector<mgx_rec_t> recs;
+    for (uint64_t t = 0; t < n_templates; ++t) {
+        const uint64_t kind = rnd() % 10;
+        mgx_rec_t a{}, b{};
+        a.coord = rnd() % (L + 1); a.prime5 = a.coord + rnd() % 5; a.flag = (uint16_t)(1 | (rnd() & 16)); a.score = (uint16_t)rnd(); a.tile = (uint16_t)t;
+        if (kind == 0) { a.mate = MGX_NO_MATE; a.flag |= 8; recs.push_back(a); continue; }             // fragment
+        if (kind == 1) { a.mate = MGX_NO_MATE; a.flag |= 4; recs.push_back(a); continue; }             // unmapped: ordering only
+        b = a; b.coord = rnd() % (L + 1); b.prime5 = kind == 2 ? ~0ull - rnd() % 7 : b.coord + rnd() % 900;  // sometimes a wrapped 5' end
+        b.flag = (uint16_t)(1 | 128 | (rnd() & 16));
+        const uint32_t i = (uint32_t)recs.size();
+        a.mate = i + 1; b.mate = i;
+        recs.push_back(a); recs.push_back(b);
+    }
+    mgx_sortdedup_routed_t* r = nullptr;
+    if (mgx_sortdedup_route(L, recs.size(), recs.data(), n_shards, -1, &r)) return 1;
+    uint64_t n_order = 0, n_mark = 0;
+    std::vector<uint32_t> order(recs.size(), 0); std::vector<uint8_t> dup(recs.size(), 0);
+    for (uint32_t k = 0; k < n_shards; ++k) {
+        mgx_sortdedup_shard_t sh;
+        if (mgx_sortdedup_routed_shard(r, k, &sh)) return 2;
+        n_order += sh.n_order; n_mark += sh.n_mark;
+        for (uint64_t i = 0; i < sh.n_mark; ++i) if (sh.mark_recs[i].mate != MGX_NO_MATE && sh.mark_recs[i].mate >= sh.n_mark) return 3;
+        std::vector<uint32_t> so(sh.order_arrival, sh.order_arrival + sh.n_order);
+        std::vector<uint8_t> sd(sh.n_mark, 1);
+        if (mgx_sortdedup_merge(r, k, so.data(), sd.data(), order.data(), dup.data())) return 4;
+    }
+    uint64_t n_nonign = 0;
+    for (auto& x : recs) if (!(x.flag & (4 | 256 | 2048))) ++n_nonign;
+    mgx_sortdedup_routed_free(r);
+    return (n_order == recs.size() && n_mark == n_nonign) ? 0 : 5;
+}
+
+static int pack_case(uint64_t n_reads, uint64_t n_haps, uint64_t n_pairs, bool cross) {
+    std::vector<uint64_t> roff(1, 0), hoff(1, 0);
+    for (uint64_t r = 0; r < n_reads; ++r) roff.push_back(roff.back() + 1 + rnd() % 40);
+    for (uint64_t h = 0; h < n_haps; ++h) hoff.push_back(hoff.back() + 1 + rnd() % 60);
+    std::vector<uint8_t> rb(roff.back(), 'A'), hb(hoff.back(), 'C');
+    std::vector<uint32_t> pr, ph;
+    for (uint64_t i = 0; i < n_pairs; ++i) { pr.push_back((uint32_t)(rnd() % n_reads)); ph.push_back((uint32_t)(rnd() % n_haps)); }
+    mgx_pairhmm_input_t in{};
+    in.n_reads = n_reads; in.read_off = roff.data(); in.bases = in.qual = in.ins = in.del = in.gcp = rb.data();
+    in.n_haps = n_haps; in.hap_off = hoff.data(); in.hap_bases = hb.data();
+    in.n_pairs = cross ? n_reads * n_haps : n_pairs; in.pair_read = cross ? nullptr : pr.data(); in.pair_hap = cross ? nullptr : ph.data();
+    const uint64_t total = cross ? n_reads * n_haps : n_pairs;
+    for (uint64_t lo = 0; lo < total; lo += 97) {
+        const uint64_t hi = lo + 97 < total ? lo + 97 : total;
+        size_t need = 0;
+        mgx_pairhmm_input_t out{};
+        if (mgx_pairhmm_pack_batch(&in, lo, hi, nullptr, 0, &out, &need) != -28) return 10;
+        std::vector<uint8_t> buf(need);
+        if (mgx_pairhmm_pack_batch(&in, lo, hi, buf.data(), buf.size(), &out, &need)) return 11;
+        if (out.n_pairs != hi - lo) return 12;
+        for (uint64_t i = 0; i < out.n_pairs; ++i) if (out.pair_read[i] >= out.n_reads || out.pair_hap[i] >= out.n_haps) return 13;
+    }
+    return 0;
+}
+
+int main() {
+    int rc = 0;
+    for (int it = 0; it < 40 && !rc; ++it) rc = route_case(1 + rnd() % 30000, 1 + (uint32_t)(rnd() % 9), 1000 + rnd() % 5000000);
+    if (!rc) rc = route_case(400000, 8, 3100000000ull);         // large enough for the router's threads to split the work
+    for (int it = 0; it < 20 && !rc; ++it) rc = pack_case(1 + rnd() % 200, 1 + rnd() % 50, rnd() % 3000, it % 3 == 0);
+    printf("host sanitize driver: rc %d\n", rc);
+    return rc;
+}

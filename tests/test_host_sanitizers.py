@@ -1,0 +1,24 @@
+"""The host-only code of the library (record packing, the multi-GPU router / merge, the PairHMM batch packer and
+its callers' validation) under AddressSanitizer + UBSan and under ThreadSanitizer, CPU build, no device: the
+translation units are compiled directly with g++ (they contain no HIP) next to a small driver."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+PKGDIR = os.path.join(ROOT, "fast-genomic-data-processing_amd")
+SRC = [os.path.join(ROOT, "tests", "cpp", "test_host_sanitize.cpp"), os.path.join(PKGDIR, "csrc", "sortdedup_route.cpp"), os.path.join(PKGDIR, "csrc", "sortdedup_pack.cpp"), os.path.join(PKGDIR, "csrc", "pairhmm_pack_batch.cpp"),
+       os.path.join(PKGDIR, "csrc", "mgx_common.cpp")]
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_host_code_under_sanitizers(tmp_path, san):
+    exe = str(tmp_path / "host_san")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + san, "-pthread",
+                           "-I", os.path.join(ROOT, "include")] + SRC + ["-o", exe])
+    env = dict(os.environ, MGX_ROUTE_THREADS="6", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1", TSAN_OPTIONS="halt_on_error=1")
+    res = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "rc 0" in res.stdout
