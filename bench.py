@@ -51,6 +51,11 @@ def host_cores():
     return cores
 
 
+def host_threads(world):
+    """Host threads one rank may use: the ranks of a node share its cores."""
+    return max(2, min(32, host_cores() // max(world, 1)))
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE)."""
@@ -90,7 +95,7 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backe
     200 M-record set on one GPU.  N > 1: the SAME set (every rank generates it from the same seed) routed into N
     coordinate shards by the host router -- records by coordinate, templates by their smaller 5' end, bitmap marks
     to the shard that owns the position -- and rank r runs shard r; no collective on the data path."""
-    recs, L = synth.gen_sortdedup_packed_fast(args.sort_records, 0x5EED0004)
+    recs, L = synth.gen_sortdedup_packed_fast(args.sort_records, 0x5EED0004, threads=host_threads(world))
     eng = pkg.SortDedupEngine(local_rank)
     route_s, shard_info = 0.0, None
     t0 = time.perf_counter()
@@ -310,11 +315,11 @@ def mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_ove
     total = args.total_pairs if world > 1 else 4 << 20
     lo, hi = shard.shard_bounds(total, rank, world)
     n_local = min(hi - lo, 4 << 20)                    # a window of the rank's shard keeps the leg short
-    d = synth.gen_pairhmm_pairs_fast(n_local, 0x5EED0003, first_pair=lo)
+    d = synth.gen_pairhmm_pairs_fast(n_local, 0x5EED0003, first_pair=lo, threads=host_threads(world))
     prepared = pkg.pairhmm.make_input(d)
     lanes = args.queue_lanes or max(2, min(8, host_cores() // world))
     q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
-    recs, L = synth.gen_sortdedup_packed_fast(max(args.sort_records // world, 1_000_000), 0x5EED0004 + rank)
+    recs, L = synth.gen_sortdedup_packed_fast(max(args.sort_records // world, 1_000_000), 0x5EED0004 + rank, threads=host_threads(world))
     eng = pkg.SortDedupEngine(local_rank)
     eng.upload(L, recs)
     q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared); eng.run(); eng.stats()
@@ -393,6 +398,7 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    os.environ.setdefault("MGX_ROUTE_THREADS", str(host_threads(world)))      # the router's threads, per rank
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
     shard = importlib.import_module(PKG + ".shard")
@@ -417,7 +423,7 @@ def main():
         what = (f"BASELINE.json configs[2]: ONE stream of {total} synthetic test cases (read 128 x hap 256, seed 0x5EED0003) split over {world} ranks "
                 f"({hi - lo} per GPU), fp32 + fp64 re-run; value = every rank's shard resident in HBM; 'queue' = the same shard streamed from host "
                 "memory through the host work queue (65536-test-case batches, PCIe-inclusive)")
-    d = synth.gen_pairhmm_pairs_fast(hi - lo, seed, first_pair=lo)      # 2a: fixed R=128, H=256
+    d = synth.gen_pairhmm_pairs_fast(hi - lo, seed, first_pair=lo, threads=host_threads(world))      # 2a: fixed R=128, H=256
     eng = pkg.PairHMMEngine(local_rank, flags=pkg.pairhmm.TIMING)
     t0 = time.perf_counter()
     batch = eng.batch(d)                               # bins + uploads: resident in HBM from here on
@@ -450,7 +456,7 @@ def main():
             # same distribution (4M test cases = 64 batches) so that it reaches its steady state
             del d
             n_local = max(total, 4 << 20)
-            d = synth.gen_pairhmm_pairs_fast(n_local, seed)
+            d = synth.gen_pairhmm_pairs_fast(n_local, seed, threads=host_threads(world))
         else:
             n_local = hi - lo
         q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
@@ -479,7 +485,7 @@ def main():
     # ---- sub-run 2b: ragged lengths R in [32,128], H in [64,256]
     if not args.no_ragged:
         n2 = hi - lo if world == 1 else min(hi - lo, 1 << 20)
-        d2 = synth.gen_pairhmm_pairs_fast(n2, 0x5EED0002 + 0x100 * rank, r_range=(32, 128), h_range=(64, 256))
+        d2 = synth.gen_pairhmm_pairs_fast(n2, 0x5EED0002 + 0x100 * rank, r_range=(32, 128), h_range=(64, 256), threads=host_threads(world))
         b2 = eng.batch(d2)
         dt2, st2 = timed_resident(eng, b2, args.steps, args.warmup, barrier)
         t2 = max_over_ranks(dt2)

@@ -1512,6 +1512,10 @@ int mgx_sortdedup_upload_chunk(mgx_sortdedup_t* c, uint64_t first_record, uint64
     if (!c->uploading) { set_error("mgx_sortdedup_upload_begin has not been called"); return -EINVAL; }
     if (n_records && !recs) { set_error("recs is NULL"); return -EINVAL; }
     if (first_record + n_records >= 0xFFFFFFF0ull) { set_error("more than 2^32 records in one shard"); return -E2BIG; }
+    if (first_record > c->up_high) {           // a gap would leave records of the device array undefined
+        set_error("chunk starts at record %llu but only %llu records have been uploaded", (unsigned long long)first_record, (unsigned long long)c->up_high);
+        return -EINVAL;
+    }
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_recs(c, (size_t)(first_record + n_records), (size_t)c->up_high);
     if (rc) return rc;

@@ -166,7 +166,9 @@ int mgx_pairhmm_regions(mgx_pairhmm_t* ctx, uint32_t n_regions, const mgx_pairhm
  * (only the reads / haplotypes its test cases reference cross PCIe, each once), uploads, launches, and
  * collects a batch's results `depth` batches later, so packing and H2D of batch k+1 overlap the kernels
  * of batch k.  Lanes of all devices share one counter; there is no collective and no device-to-device
- * traffic.  Results are identical to mgx_pairhmm_compute on the whole stream. */
+ * traffic.  Results are identical to mgx_pairhmm_compute on the whole stream.  A queue runs one stream at a time
+ * (its run functions are not re-entrant); the caller's thread works as lane 0, the other lanes are threads the
+ * run starts and joins. */
 typedef struct mgx_pairhmm_queue mgx_pairhmm_queue_t;
 typedef struct mgx_pairhmm_queue_config {
     uint32_t n_devices;         /* 0 = one device, ordinal 0 */

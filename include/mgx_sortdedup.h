@@ -101,7 +101,8 @@ int mgx_sortdedup_upload(mgx_sortdedup_t* ctx, uint64_t L, uint64_t n_records, c
  * feeds its shuffle threads through a bounded queue of line blocks, sortmardup/main.cpp:505-562; here the pieces go
  * straight to the device, so parsing, staging and the PCIe copy overlap):
  *   begin   n_expected is a capacity hint (0 is fine; the device array grows when a chunk exceeds it)
- *   chunk   records [first_record, first_record + n_records) in arrival order; mate indices are GLOBAL arrival
+ *   chunk   records [first_record, first_record + n_records) in arrival order, without gaps (first_record may not lie
+ *           beyond what has been uploaded so far; re-sending a range overwrites it); mate indices are GLOBAL arrival
  *           indices; returns once the caller's buffer may be reused (the device copy continues in the background)
  *   end     n_records must equal the extent the chunks covered; waits for the copies */
 int mgx_sortdedup_upload_begin(mgx_sortdedup_t* ctx, uint64_t L, uint64_t n_expected);
