@@ -1263,20 +1263,50 @@ int mgx_pairhmm_compute_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_
         if (regions[g].n_reads * regions[g].n_haps && !out_log10[g]) { set_error("region %u: output pointer is NULL", g); return -EINVAL; }
     }
     HIP_TRY(hipSetDevice(c->device));
-    BatchPtr b = new_batch();
-    if (!b) return -ENOMEM;
-    std::vector<uint64_t> base;
-    if ((rc = create_cross_multi(c, n_regions, regions, b.get(), &base))) return rc;
-    if (b->n_pairs == 0) return 0;
-    mgx_pairhmm_batch_t* raw = b.release();
-    rc = mgx_pairhmm_batch_run(c, raw);
-    if (!rc) rc = fetch_results(c, raw, raw->n_pairs * sizeof(double));
-    if (!rc) {
-        const double* all = (const double*)(raw->slab.pin + raw->o_out);
-        for (uint32_t g = 0; g < n_regions; ++g)
-            if (base[g + 1] > base[g]) memcpy(out_log10[g], all + base[g], (base[g + 1] - base[g]) * sizeof(double));
+    // A large call is cut into runs of whole regions of about kChunkPairs test cases that go through the context two
+    // at a time: while one chunk computes, the next is flattened and uploaded and the previous one's results are
+    // scattered -- the queue's pipelining (mgx_pairhmm_queue_run_regions) on the caller's thread alone.
+    constexpr uint64_t kChunkPairs = 1u << 17;
+    std::vector<uint32_t> cut(1, 0);
+    {
+        uint64_t in_chunk = 0;
+        for (uint32_t g = 0; g < n_regions; ++g) {
+            const uint64_t n = regions[g].n_reads * regions[g].n_haps;
+            if (in_chunk && in_chunk + n > kChunkPairs) { cut.push_back(g); in_chunk = 0; }
+            in_chunk += n;
+        }
+        cut.push_back(n_regions);
     }
-    mgx_pairhmm_batch_destroy(c, raw);
+    struct InFlight { mgx_pairhmm_batch_t* b = nullptr; uint32_t g0 = 0, g1 = 0; std::vector<uint64_t> base; };
+    InFlight fl[2];
+    auto retire = [&](InFlight& f) -> int {
+        if (!f.b) return 0;
+        int r = fetch_results(c, f.b, f.b->n_pairs * sizeof(double));
+        if (!r) {
+            const double* all = (const double*)(f.b->slab.pin + f.b->o_out);
+            for (uint32_t g = f.g0; g < f.g1; ++g) {
+                const uint64_t a = f.base[g - f.g0], e = f.base[g - f.g0 + 1];
+                if (e > a) memcpy(out_log10[g], all + a, (e - a) * sizeof(double));
+            }
+        }
+        mgx_pairhmm_batch_destroy(c, f.b);
+        f.b = nullptr;
+        return r;
+    };
+    rc = 0;
+    for (size_t k = 0; k + 1 < cut.size() && !rc; ++k) {
+        InFlight& f = fl[k & 1];
+        rc = retire(f);                                  // the chunk launched two iterations ago
+        if (rc) break;
+        BatchPtr b = new_batch();
+        if (!b) { rc = -ENOMEM; break; }
+        f.g0 = cut[k]; f.g1 = cut[k + 1];
+        if ((rc = create_cross_multi(c, f.g1 - f.g0, regions + f.g0, b.get(), &f.base))) break;
+        if (b->n_pairs == 0) continue;
+        f.b = b.release();
+        rc = mgx_pairhmm_batch_run(c, f.b);
+    }
+    for (int q = 0; q < 2; ++q) { const int r = retire(fl[(cut.size() - 1 + q) & 1]); if (!rc) rc = r; }   // oldest first
     return rc;
 }
 
