@@ -230,6 +230,122 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwJob* __restrict__ jobs,
     for (int q = 0; q <= w && q < n_compact; ++q) { ce[2 * q] = el[2 * q]; ce[2 * q + 1] = el[2 * q + 1]; }
 }
 
+// The same with one WAVEFRONT per pair.  A lane per pair walks ~275 dependent byte loads of ~2 us each with a third of
+// a wavefront per SIMD to hide them behind; here the 64 lanes fetch the next 64 cells of the current DIAGONAL in one
+// gather (lane t: cell (i - t, j - t)) and the walk consumes them from registers, so an alignment of a few hundred
+// matches with a handful of gaps costs a handful of memory round trips.  Inside a gap (extension states) cells are
+// loaded one at a time as before.  The walk itself is wave-uniform; elements are merged on the fly (run-length form,
+// which is what the reference's final merge pass produces, PairWiseSW.h:390-408) and written by lane 0.
+__global__ __launch_bounds__(64) void k_sw_trace_wave(const SwJob* __restrict__ jobs, u32 n, const u8* __restrict__ bt,
+                                                      const int32_t* __restrict__ sc, int16_t* __restrict__ elems_all, SwResult* __restrict__ res,
+                                                      int16_t* __restrict__ compact, int n_compact) {
+    const u32 p = blockIdx.x;
+    if (p >= n) return;
+    const int lane = threadIdx.x;
+    const SwJob J = jobs[p];
+    const int nrow = (int)J.len1, ncol = (int)J.len2, strategy = (int)J.strategy, rpl = (int)J.rpl, g = (int)J.g;
+    const int32_t* last_row = sc + J.sc_off;
+    const int32_t* last_col = last_row + ncol + 1;
+    const u8* btp = bt + J.bt_off;
+    int16_t* el = elems_all + J.el_off;
+    const bool use_row = strategy == MGX_SW_SOFTCLIP || strategy == MGX_SW_IGNORE;
+    // ---- best end cell (PairWiseSW.h:256-285).  The maximum first, in parallel; then the cells that reach it are
+    //      replayed in anti-diagonal order (row candidate before column candidate), which is all the tie rules see.
+    int best = INT32_MIN;
+    if (use_row) for (int j = 1 + lane; j <= ncol; j += 64) best = max(best, last_row[j]);
+    for (int i = 1 + lane; i <= nrow; i += 64) best = max(best, last_col[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+    int mi = 0, mj = 0;
+    bool have = false;
+    for (int d0 = 1; d0 <= nrow + ncol; d0 += 64) {
+        const int d = d0 + lane;
+        const int ja = d - nrow, ib = d - ncol;
+        const bool eq_a = use_row && d <= nrow + ncol && ja >= 1 && last_row[ja] == best;
+        const bool eq_b = d <= nrow + ncol && ib >= 1 && last_col[ib] == best;
+        const u64 ma = __ballot(eq_a), mb = __ballot(eq_b);
+        u64 any = ma | mb;
+        while (any) {
+            const int t = __ffsll((long long)any) - 1;
+            any &= any - 1;
+            const int dd = d0 + t;
+            if ((ma >> t) & 1) {
+                const int j = dd - nrow;
+                if (!have || abs(nrow - j) < abs(mi - mj)) { mi = nrow; mj = j; have = true; }
+            }
+            if ((mb >> t) & 1) {
+                const int i = dd - ncol;
+                if (!have || mj == ncol || abs(i - ncol) <= abs(mi - mj)) { mi = i; mj = ncol; have = true; }
+            }
+        }
+    }
+    // ---- back-trace (PairWiseSW.h:299-408), elements in run-length form
+    int i, j;
+    if (strategy == MGX_SW_INDEL) { i = nrow; j = ncol; }
+    else if (strategy == MGX_SW_LEADING_INDEL) { i = mi; j = ncol; }
+    else { i = mi; j = mj; }
+    int m = 0;                    // elements written so far
+    int cur_op = -1, cur_len = 0; // the open element
+    auto flush = [&]() {
+        if (cur_op >= 0) { if (lane == 0) { el[2 * m] = (int16_t)cur_op; el[2 * m + 1] = (int16_t)cur_len; } ++m; }
+    };
+    auto push = [&](int op, int len) {          // append, merging with the open element
+        if (op == cur_op) cur_len += len;
+        else { flush(); cur_op = op; cur_len = len; }
+    };
+    if (j < ncol) push(MGX_SW_SOFTCLIP, ncol - j);
+    auto cell_index = [&](int ii, int jj) -> size_t {
+        const int l = (ii - 1) / rpl, k = (ii - 1) - l * rpl;
+        return ((size_t)(jj + l) * g + l) * rpl + k;
+    };
+    int state = 0;
+    int c_i = 0, c_j = 0;         // the cached diagonal starts at (c_i, c_j): lane t holds cell (c_i - t, c_j - t)
+    int cached = 0;
+    bool valid = false;
+    while (i > 0 && j > 0) {
+        int btr;
+        if (state == 0) {
+            int t = c_i - i;
+            if (!valid || t < 0 || t >= 64 || c_j - j != t) {
+                c_i = i; c_j = j; valid = true; t = 0;
+                const int ii = i - lane, jj = j - lane;
+                cached = (ii >= 1 && jj >= 1) ? (int)btp[cell_index(ii, jj)] : 0;
+            }
+            btr = __builtin_amdgcn_readlane(cached, __builtin_amdgcn_readfirstlane(t));
+        } else {
+            btr = btp[cell_index(i, j)];
+        }
+        if (state == kInsertExt) { --j; cur_len++; state = btr & kInsertExt; }
+        else if (state == kDeleteExt) { --i; cur_len++; state = btr & kDeleteExt; }
+        else {
+            const int op = btr & 3;
+            if (op == kOpMatch) { --i; --j; push(kOpMatch, 1); state = 0; }
+            else if (op == kOpInsert) { --j; push(kOpInsert, 1); state = btr & kInsertExt; }
+            else { --i; push(kOpDelete, 1); state = btr & kDeleteExt; }
+        }
+    }
+    int offset;
+    if (strategy == MGX_SW_SOFTCLIP) {
+        if (j > 0) push(MGX_SW_SOFTCLIP, j);
+        offset = i;
+    } else if (strategy == MGX_SW_IGNORE) {
+        if (j > 0) push(cur_op, j);             // "the last element once more, j long"
+        offset = (int16_t)(i - j);
+    } else {
+        if (i > 0) push(kOpDelete, i);
+        else if (j > 0) push(kOpInsert, j);
+        offset = 0;
+    }
+    flush();
+    if (lane == 0) {
+        SwResult r; r.score = best; r.max_i = mi; r.max_j = mj; r.offset = offset; r.n_elems = m;
+        res[J.out_index] = r;
+    }
+    __syncthreads();                             // lane 0's element stores before the block's lanes copy them
+    int16_t* ce = compact + (size_t)J.out_index * 2 * n_compact;
+    for (int q = lane; q < 2 * min(m, n_compact); q += 64) ce[q] = el[q];
+}
+
 // alignments with more than kCompactElems elements: their element lists are packed densely for one download
 struct GatherRef { u64 src, dst; u32 n; u32 pad_; };     // int16 offsets, n = number of int16 values
 __global__ __launch_bounds__(256) void k_sw_gather(const GatherRef* __restrict__ refs, u32 n_refs, const int16_t* __restrict__ el,
@@ -416,8 +532,13 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         a = b;
     }
     HIP_TRY(hipEventRecord(c->ev[1], s));
-    hipLaunchKernelGGL(k_sw_trace, dim3((n + 63) / 64), dim3(64), 0, s, c->d_jobs.p, n, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
-                       c->d_cel.p, kCompactElems);
+    static const bool lane_trace = [] { const char* e = getenv("MGX_SW_TRACE"); return e && !strcmp(e, "lane"); }();   // A/B: one lane per pair
+    if (lane_trace)
+        hipLaunchKernelGGL(k_sw_trace, dim3((n + 63) / 64), dim3(64), 0, s, c->d_jobs.p, n, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
+                           c->d_cel.p, kCompactElems);
+    else
+        hipLaunchKernelGGL(k_sw_trace_wave, dim3(n), dim3(64), 0, s, c->d_jobs.p, n, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
+                           c->d_cel.p, kCompactElems);
     HIP_TRY(hipEventRecord(c->ev[2], s));
     HIP_TRY(hipGetLastError());
     std::vector<SwResult> res(n);

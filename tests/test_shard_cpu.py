@@ -108,3 +108,19 @@ def test_route_rejects_bad_input(pkg, synth):
     bad = recs.copy(); bad["mate"][10] = 5000
     with pytest.raises(pkg.MgxError):
         pkg.Routed(L, bad, 2)
+
+
+def test_route_degenerate_inputs(pkg, sd_oracle, synth):
+    """No records at all, a single fragment, more shards than records."""
+    empty = np.zeros(0, dtype=synth.REC_DTYPE)
+    r = pkg.Routed(1000, empty, 3)
+    for k in range(3):
+        sh = r.shard_arrays(k)
+        assert len(sh["order_coord"]) == len(sh["mark_recs"]) == len(sh["marks"]) == 0
+    r.close()
+    raw = synth.gen_sortdedup_raw(3, 1, n_contigs=1, contig_len=5000)
+    recs, idx, L = pkg.sortdedup.pack(raw)
+    want_order, want_dup, _ = sd_oracle.run(L, recs)
+    for k_shards in (1, 5, 64):
+        order, dup, info = sharded(pkg, lambda rr, k, sh: sd_oracle.run_shard(L, sh), L, recs, k_shards)
+        assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
