@@ -448,7 +448,7 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
     b->result_bytes = off - b->o_out;
     const size_t pin_bytes = off;              // the pinned mirror covers the inputs and the results only
     const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
-    const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
+    const size_t o_rlist = off; off = align_up(off + 2 * n * sizeof(uint32_t));   // fp64 re-run lists | exact-tier list
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
     if ((rc = acquire_slab(c, off, pin_bytes, &b->slab))) return rc;
     uint8_t* dv = b->slab.dev; uint8_t* pin = b->slab.pin;
@@ -471,7 +471,6 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
     hipStream_t s = c->copy;
     if (model) {
         for (uint64_t r = 0; r < nr; ++r) {
-            if (in->read_off[r + 1] - in->read_off[r] > 1024) { set_error("read longer than 1024 bases"); return -E2BIG; }
             ((uint64_t*)(pin + o_rlen))[r] = in->read_off[r + 1] - in->read_off[r];
         }
         memcpy(pin + o_mapq, mapq, nr);
@@ -611,7 +610,7 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
     b->result_bytes = off - b->o_out;
     const size_t pin_bytes = off;              // the pinned mirror covers the inputs and the results only
     const size_t o_jobs = off;  off = align_up(off + n * sizeof(Job));
-    const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
+    const size_t o_rlist = off; off = align_up(off + 2 * n * sizeof(uint32_t));   // fp64 re-run lists | exact-tier list
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
     if ((rc = acquire_slab(c, off, pin_bytes, &b->slab))) return rc;
     uint8_t* dv = b->slab.dev; uint8_t* pin = b->slab.pin;
@@ -668,7 +667,6 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
             if (in.n_reads && !mapq[g]) { set_error("region %u: mapq is NULL", g); return -EINVAL; }
             for (uint64_t r = 0; r < in.n_reads; ++r) {
                 const uint64_t len = in.read_off[r + 1] - in.read_off[r];
-                if (len > 1024) { set_error("read longer than 1024 bases"); return -E2BIG; }
                 rlen[r_at + r] = len;
                 roff[r_at + r] = (uint32_t)((*out_base)[g] + r * in.n_haps);
                 rnh[r_at + r] = (uint32_t)in.n_haps;
@@ -782,7 +780,7 @@ int create_pairs(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const mgx::Pac
     b->o_out = off;             off = align_up(off + n * sizeof(double));
     b->o_used = off;            off = align_up(off + n);
     b->result_bytes = off - b->o_out;
-    const size_t o_rlist = off; off = align_up(off + n * sizeof(uint32_t));
+    const size_t o_rlist = off; off = align_up(off + 2 * n * sizeof(uint32_t));   // fp64 re-run lists | exact-tier list
     const size_t o_rcount = off; off = align_up(off + 64 * sizeof(uint32_t));
     const bool staged = plan || o_rlist <= kStageLimit;
     if ((rc = acquire_slab(c, off, staged ? o_rlist : 0, &b->slab))) return rc;
@@ -932,6 +930,8 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         narrow_rows = std::max(narrow_rows, (uint32_t)(bn.G * bn.RPL));
     }
     constexpr int kSharedCount = 63;                       // counter slot of the shared list
+    constexpr int kExactCount = 62;                        // ... and of the exact tier's list (second half of d_rerun_list)
+    uint32_t* const d_exact_list = b->d_rerun_list + b->n_pairs;
     KernelArgs base{};
     base.jobs = b->d_jobs;
     base.bases = b->d_bases; base.qual = b->d_qual; base.ins = b->d_ins; base.del = b->d_del;
@@ -941,6 +941,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     base.log10_initial_d = c->log10_initial_d;
     auto launch_f64 = [&](KernelArgs a, int Gd, int RPLd, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t sk) -> int {
         a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d; a.ph2pr_div3 = c->d_div3_d; a.gap_ratio = c->d_ratio_d;
+        a.rerun_list = d_exact_list; a.rerun_count = b->d_rerun_count + kExactCount;      // job_list / n_dyn are set: the fp64 tier appends here
         KernelFn f = a.strip_scratch ? (KernelFn)pairhmm_fwd_strip<double> : pick_kernel<double>(Gd, RPLd);
         if (!f) { set_error("no fp64 kernel for G=%d RPL=%d", Gd, RPLd); return -ENOSYS; }
         hipLaunchKernelGGL(f, dim3(grid), dim3(block), lds, sk, a);
@@ -1062,6 +1063,29 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         if (rc) return rc;
         if (timing) HIP_TRY(hipEventRecord(ev[4 * first_narrow + 3], s));
     }
+    {
+        // The exact tier: whatever the fp64 launches left within reach of the flush-to-zero threshold (next to nothing
+        // on real data: log10 likelihoods below about -587), one test case per wavefront, the reference's operation order.
+        uint32_t max_h = 0;
+        for (const Bin& bn : b->bins) max_h = std::max(max_h, bn.max_h);
+        KernelArgs a = base;
+        a.ph2pr = c->d_ph2pr_d; a.mm = c->d_mm_d; a.ph2pr_div3 = c->d_div3_d; a.gap_ratio = c->d_ratio_d;
+        a.job_list = d_exact_list; a.n_dyn = b->d_rerun_count + kExactCount; a.n_static = 0; a.job_first = 0;
+        a.rerun_list = nullptr; a.rerun_count = nullptr;
+        a.lds_stride = (max_h + 2u * 64u + 8u + 15u) & ~15u;
+        a.strip_stride = (max_h + 63u) & ~63u;
+        const size_t per_wg = 6u * (size_t)a.strip_stride * sizeof(double);
+        const uint32_t grid = (uint32_t)std::max<size_t>(1, std::min<size_t>({(size_t)b->n_pairs, (size_t)c->n_cu * 2u, (size_t)(256u << 20) / per_wg}));
+        const size_t need = (size_t)grid * per_wg;
+        if (need > c->strip_cap) {
+            HIP_TRY(hipStreamSynchronize(s));
+            (void)hipFree(c->d_strip); c->d_strip = nullptr; c->strip_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_strip, need));
+            c->strip_cap = need;
+        }
+        a.strip_scratch = c->d_strip;
+        hipLaunchKernelGGL(pairhmm_fwd_exact, dim3(grid), dim3(64), a.lds_stride, s, a);
+    }
     if (b->has_model && b->d_row_off)
         hipLaunchKernelGGL(pairhmm_normalize_filter_rows, dim3((b->n_reads + 3) / 4), dim3(256), 0, s, b->d_out, b->d_read_len,
                            b->d_row_off, b->d_row_nh, b->n_reads, b->log10_rate, b->max_err, b->d_keep);
@@ -1097,6 +1121,7 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, mgx_pairhm
         HIP_TRY(hipMemcpy(cnt.data(), b->d_rerun_count, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (size_t k = 0; k < b->bins.size(); ++k) st.n_rerun_f64 += force_f64 ? b->bins[k].job_count : cnt[k];
         if (!force_f64) st.n_rerun_f64 += cnt[63];          // the narrow classes' shared list
+        st.n_exact = cnt[62];
     }
     st.ms_f32 = st.ms_f64 = st.ms_f32_dominant = 0;
     st.dominant_cells = st.dominant_alg_bytes = 0;

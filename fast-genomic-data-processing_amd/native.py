@@ -29,7 +29,7 @@ class PairHMMStats(C.Structure):
         ("n_rerun_f64", C.c_uint64), ("n_launches_f32", C.c_uint32), ("n_launches_f64", C.c_uint32),
         ("n_runs_timed", C.c_uint32), ("ms_f32", C.c_float), ("ms_f64", C.c_float), ("ms_f32_dominant", C.c_float),
         ("dominant_cells", C.c_uint64), ("dominant_alg_bytes", C.c_uint64),
-        ("dominant_kernel", C.c_char * 64),
+        ("dominant_kernel", C.c_char * 64), ("n_exact", C.c_uint64),
     ]
 
 

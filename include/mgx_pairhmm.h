@@ -23,8 +23,8 @@
  * (haplotypecaller/ReadForPairHMM.cpp:18-38): bases, base quals, insertion GOP, deletion GOP,
  * gap-continuation penalty.  Every quality byte is masked with 127 on the device exactly as the
  * reference does; bases are ASCII, any byte other than A/C/G/T/N is treated as 'A'
- * (pairhmm_common.h:75-81).  Reads may be up to 2^20 bases long (beyond 1024 a strip-mined kernel is used; the
- * whole-region call mgx_pairhmm_region(s) takes reads up to 1024 bases), haplotypes up to about 40 000 bases;
+ * (pairhmm_common.h:75-81).  Reads may be up to 2^20 bases long (beyond 1024 a strip-mined kernel is used),
+ * haplotypes up to about 40 000 bases;
  * longer sequences are rejected with -E2BIG.
  *
  * All functions return 0 on success or a negative errno-style code; no exception crosses the
@@ -92,6 +92,8 @@ typedef struct mgx_pairhmm_stats {
     uint64_t dominant_cells;   /* ... and the cells / algorithmic bytes it processed */
     uint64_t dominant_alg_bytes;
     char dominant_kernel[64];  /* its name as rocprofv3 prints it (prefix) */
+    uint64_t n_exact;          /* test cases whose fp64 result was < 1e-280 (in reach of the flush-to-zero threshold) and
+                                * that were computed a third time in the reference's exact operation order (last run) */
 } mgx_pairhmm_stats_t;
 
 const char* mgx_last_error(void);

@@ -270,3 +270,51 @@ def test_long_and_short_reads_in_one_region(engine, oracle, synth):
     got = engine.compute(dict(d, pair_read=None, pair_hap=None))
     assert_log10_close(got, want)
     assert np.array_equal(engine.compute_regions([d])[0].ravel(), got)
+
+
+def flush_regime_pairs(seed, n, r_lens=(151, 200, 300, 400, 700, 1100)):
+    """Reads cut from their haplotype with so many high-quality mismatches that the fp64 likelihood lands around
+    2^-1022 * 2^1020 (log10 between about -560 and -660): below, at and above the flush-to-zero threshold."""
+    rng = np.random.RandomState(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads, haps, quals = [], [], []
+    for i in range(n):
+        R = int(r_lens[i % len(r_lens)])
+        H = R + int(rng.randint(0, 120))
+        hap = acgt[rng.randint(0, 4, H)]
+        at = int(rng.randint(0, H - R + 1))
+        read = hap[at:at + R].copy()
+        q = int(rng.choice([q_ for q_ in (60, 70, 80, 93) if R * q_ >= 7000] or [93]))
+        per = q / 10.0 + 0.477
+        k = min(R, int(round((560 + 100 * rng.rand()) / per)))          # mismatches wanted
+        pos = rng.choice(R, k, replace=False)
+        read[pos] = acgt[(np.searchsorted(acgt, read[pos]) + 1 + rng.randint(0, 3, k)) % 4]
+        reads.append(read); haps.append(hap); quals.append(np.full(R, q, dtype=np.uint8))
+    ro = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    ho = np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.uint64)
+    nb = int(ro[-1])
+    return {"read_off": ro, "hap_off": ho, "bases": np.concatenate(reads), "qual": np.concatenate(quals),
+            "ins": rng.randint(85, 94, nb).astype(np.uint8), "dele": rng.randint(85, 94, nb).astype(np.uint8),
+            "gcp": np.concatenate(quals),          # gaps as dear as mismatches: no cheap way round them
+ "hap_bases": np.concatenate(haps),
+            "pair_read": np.arange(n, dtype=np.uint32), "pair_hap": np.arange(n, dtype=np.uint32),
+            "cells": int(sum(len(r) * len(h) for r, h in zip(reads, haps)))}
+
+
+def test_results_near_the_flush_to_zero_threshold(pkg, engine, oracle):
+    """Flush-to-zero is on in the reference (IntelPairHmm.cc:230): a likelihood within reach of 2^-1022 depends on which
+    intermediate products were flushed, so fp64 results below 1e-280 are computed again in the reference's exact
+    operation order (unfused, plain form).  The outcome, including which test cases end as -inf, equals the oracle's."""
+    d = flush_regime_pairs(5, 240)
+    want, _ = oracle.batch(d)
+    fin = np.isfinite(want)
+    assert fin.any() and (~fin).any() and (want[fin] < -600).any()         # the sample straddles the threshold
+    out, used, st = run(engine, d)
+    assert used.all()
+    assert st["n_exact"] >= int((~fin).sum()) and st["n_exact"] >= int((want[fin] < -590).sum())
+    assert_log10_close(out, want)
+    # forced double precision takes the same third tier
+    eng64 = pkg.PairHMMEngine(0, flags=pkg.pairhmm.FORCE_DOUBLE)
+    out64, _, st64 = run(eng64, d)
+    eng64.close()
+    assert np.array_equal(out64, out) and st64["n_exact"] == st["n_exact"]

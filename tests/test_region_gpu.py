@@ -12,9 +12,9 @@ from test_pairhmm_oracle import assert_log10_close
 pytestmark = pytest.mark.gpu
 
 
-def repeat_rich_region(synth, n_reads, n_haps, seed):
+def repeat_rich_region(synth, n_reads, n_haps, seed, r_range=(30, 151), h_range=(120, 300)):
     """Reads full of homopolymers and short tandem repeats (what the PCR error model keys on)."""
-    d = synth.gen_pairhmm_region(n_reads, n_haps, seed, r_range=(30, 151), h_range=(120, 300))
+    d = synth.gen_pairhmm_region(n_reads, n_haps, seed, r_range=r_range, h_range=h_range)
     rng = np.random.RandomState(seed)
     bases = d["bases"].copy()
     ro = d["read_off"].astype(np.int64)
@@ -73,6 +73,27 @@ def test_region_matches_oracle_pipeline(engine, oracle, synth, n_reads, n_haps, 
     if n_haps > 1:
         assert np.all(got >= best[:, None] - 4.5 - 1e-9)                          # capped
         assert (keep == 0).any() or n_reads < 20                                   # some random reads are dropped
+
+
+def test_region_long_reads(engine, oracle, synth):
+    """Reads past 1024 bases (the strip-mined class): the read model looks for tandem repeats in global
+    memory instead of the LDS copy; same checks as above."""
+    n_reads, n_haps = 24, 5
+    d, mapq = repeat_rich_region(synth, n_reads, n_haps, 21, r_range=(700, 2600), h_range=(900, 3000))
+    assert np.diff(d["read_off"].astype(np.int64)).max() > 1024
+    mod, olib = oracle_model(d, mapq)
+    dm = dict(d); dm.update(mod)
+    dm_cross = dict(dm); dm_cross["pair_read"] = None; dm_cross["pair_hap"] = None
+    raw, _ = engine.region(d, mapq, log10_mismapping_rate=float("-inf"))
+    assert np.array_equal(raw.ravel(), engine.compute(dm_cross))
+    want, _ = oracle.batch(dm)
+    assert_log10_close(raw.ravel(), want)
+    # and in one batch with short-read regions
+    d2, mapq2 = repeat_rich_region(synth, 40, 9, 22)
+    got = engine.regions([d2, d, d2], [mapq2, mapq, mapq2])
+    for (o, k), (dd, mq) in zip(got, [(d2, mapq2), (d, mapq), (d2, mapq2)]):
+        wo, wk = engine.region(dd, mq)
+        assert np.array_equal(o, wo) and np.array_equal(k, wk)
 
 
 def test_region_model_off(engine, synth):
