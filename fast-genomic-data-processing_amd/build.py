@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgx.so")
-SOURCES = ["mgx_common.cpp", "mgx_tables.cpp", "sortdedup_pack.cpp", "sortdedup_route.cpp", "pairhmm_pack_batch.cpp", "mgx_pairhmm.hip", "mgx_sortdedup.hip", "mgx_smithwaterman.hip"]
+SOURCES = ["mgx_common.cpp", "mgx_tables.cpp", "sortdedup_pack.cpp", "sortdedup_route.cpp", "pairhmm_pack_batch.cpp", "mgx_pairhmm.hip", "mgx_sortdedup.hip", "mgx_smithwaterman.hip", "mgx_bgzf.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fgpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-ffp-contract=off",
          # the reference runs with MXCSR.FTZ set (IntelPairHmm.cc:230), which flushes fp64 results too
          "-Xarch_device", "-fdenormal-fp-math=preserve-sign",

@@ -182,3 +182,25 @@ SMITHWATERMAN_SYMBOLS = {
     "mgx_sw_stats": (C.c_int, [C.c_void_p, C.POINTER(SwStats)]),
 }
 SYMBOLS.update(SMITHWATERMAN_SYMBOLS)
+
+
+# ---- include/mgx_bgzf.h ---------------------------------------------------------------------------
+class BgzfStats(C.Structure):
+    _fields_ = [("n_blocks", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64), ("n_stored", C.c_uint64),
+                ("ms_kernels", C.c_float)]
+
+
+BGZF_SYMBOLS = {
+    "mgx_bgzf_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
+    "mgx_bgzf_destroy": (None, [C.c_void_p]),
+    "mgx_bgzf_batch_create": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "mgx_bgzf_batch_destroy": (None, [C.c_void_p, C.c_void_p]),
+    "mgx_bgzf_batch_input": (C.c_void_p, [C.c_void_p]),
+    "mgx_bgzf_batch_offsets": (C.c_void_p, [C.c_void_p]),
+    "mgx_bgzf_batch_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "mgx_bgzf_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mgx_bgzf_bound": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "mgx_bgzf_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mgx_bgzf_stats": (C.c_int, [C.c_void_p, C.POINTER(BgzfStats)]),
+}
+SYMBOLS.update(BGZF_SYMBOLS)

@@ -1,0 +1,67 @@
+/*
+ * mgx_bgzf.h -- C ABI of the MI355X BGZF block compressor (libmgx.so), SURVEY.md section 8f row F3.
+ *
+ * Drop-in seam: the reference's writer threads hand every 64 KB of BAM bytes to htslib's
+ * bgzf_compress (deepmutect/htslib/bgzf.c:610-648, called from deflate_block, bgzf.c:695-707, by
+ * sortmardup/main.cpp:371-421), which runs zlib's deflate on one CPU thread per slice -- ~80 % of the
+ * wall time of a coordinate sort on this machine.  Here a batch of blocks is compressed on the device:
+ * one workgroup per BGZF block (LZ77 matching through an LDS hash table, greedy/lazy parse, dynamic
+ * Huffman codes built per block, CRC-32), and the finished blocks come back packed back to back.
+ *
+ * Every block is a complete gzip member with the BGZF extra field (SAMv1 section 4.1): any inflater
+ * returns the input bytes.  The compressed BYTES are this implementation's own (as they are zlib's own in
+ * the reference, and depend on its level and version); what is identical to the reference is the
+ * uncompressed stream.
+ *
+ * All functions return 0 or a negative errno-style code; mgx_last_error() has the message.
+ */
+#ifndef MGX_BGZF_H
+#define MGX_BGZF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_bgzf mgx_bgzf_t;
+typedef struct mgx_bgzf_batch mgx_bgzf_batch_t;
+
+#define MGX_BGZF_MAX_BLOCK_IN 0xff00u      /* uncompressed bytes per block (htslib's BGZF_BLOCK_SIZE) */
+#define MGX_BGZF_MAX_BLOCK_OUT 0x10000u    /* upper bound of one finished block */
+
+const char* mgx_last_error(void);
+
+int mgx_bgzf_create(int device, unsigned flags, mgx_bgzf_t** out);
+void mgx_bgzf_destroy(mgx_bgzf_t* ctx);
+
+/* A batch owns a pinned input buffer the caller fills (uncompressed bytes of consecutive blocks and their
+ * n_blocks + 1 offsets), device memory, and a pinned output buffer.  Several batches may be in flight on
+ * one context: submit() only enqueues (H2D, kernels, D2H of the offsets and of the packed blocks). */
+int mgx_bgzf_batch_create(mgx_bgzf_t* ctx, uint64_t in_capacity, uint32_t max_blocks, mgx_bgzf_batch_t** out);
+void mgx_bgzf_batch_destroy(mgx_bgzf_t* ctx, mgx_bgzf_batch_t* b);
+uint8_t* mgx_bgzf_batch_input(mgx_bgzf_batch_t* b);        /* [in_capacity] */
+uint64_t* mgx_bgzf_batch_offsets(mgx_bgzf_batch_t* b);     /* [max_blocks + 1], offsets[0] = 0, block i = [offsets[i], offsets[i+1]) */
+/* offsets[i+1] - offsets[i] <= MGX_BGZF_MAX_BLOCK_IN (an empty block is allowed and yields an empty gzip member) */
+int mgx_bgzf_batch_submit(mgx_bgzf_t* ctx, mgx_bgzf_batch_t* b, uint32_t n_blocks);
+/* Waits for the batch.  *out = the finished blocks back to back (pinned memory owned by the batch, valid until
+ * the next submit), out_offsets[i] = start of block i in it, out_offsets[n_blocks] = total bytes. */
+int mgx_bgzf_batch_wait(mgx_bgzf_t* ctx, mgx_bgzf_batch_t* b, const uint8_t** out, const uint64_t** out_offsets);
+
+/* One shot over pageable memory: pieces [offsets[i], offsets[i+1]) of `in` -> BGZF blocks appended to `out`
+ * (capacity out_capacity >= mgx_bgzf_bound(n_bytes, n_blocks)); out_offsets has n_blocks + 1 entries. */
+uint64_t mgx_bgzf_bound(uint64_t n_bytes, uint64_t n_blocks);
+int mgx_bgzf_compress(mgx_bgzf_t* ctx, const uint8_t* in, const uint64_t* offsets, uint64_t n_blocks, uint8_t* out,
+                      uint64_t out_capacity, uint64_t* out_offsets);
+
+typedef struct mgx_bgzf_stats {
+    uint64_t n_blocks, bytes_in, bytes_out;   /* since create */
+    uint64_t n_stored;                        /* blocks emitted as stored (incompressible) */
+    float ms_kernels;                         /* last batch waited for: deflate + pack kernels (HIP events) */
+} mgx_bgzf_stats_t;
+int mgx_bgzf_stats(mgx_bgzf_t* ctx, mgx_bgzf_stats_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
