@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -49,7 +50,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-constexpr int kNT = 256;                       // threads per workgroup = positions per match window
+constexpr int kNT = 1024;                      // threads per workgroup = positions per match window (16 wavefronts: one block per CU, LDS-bound)
 constexpr int kHashBits = 12;
 constexpr u32 kMaxIn = MGX_BGZF_MAX_BLOCK_IN;
 constexpr u32 kSlot = 0x10000;                 // bytes of device scratch per finished block
@@ -57,8 +58,9 @@ constexpr u32 kSlotSkew = 2;                   // a block starts at slot + 2: it
 constexpr u32 kPad = 320;                      // zero bytes after the input in LDS (match extension reads ahead)
 constexpr u32 kCrcPoly = 0xEDB88320u;
 constexpr int kNumLL = 286, kNumD = 30, kNumCL = 19;
+constexpr u32 kScratchPerWg = 65536u + 64u;     // u32 per workgroup: decided matches, then packed tokens, by position
 
-enum { V_OVER = 0, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
+enum { V_OVER = 0, V_NUSED, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
 
 struct __attribute__((aligned(16))) Lds {
     u32 buf[(0x10000 + 512) / 4];              // the block's bytes (at the source's alignment), later the output words
@@ -73,7 +75,12 @@ struct __attribute__((aligned(16))) Lds {
     u16 parent[576];
     u8 depth[576];
     u32 bl_count[16], next_code[16];
-    u32 scan[kNT];
+    u32 wsum[kNT / 64];
+    u16 cand[2][kNT];                          // hash candidates (position + 1) of the current and the next window
+    u32 cend[kNT];                             // parse: where chunk t's last token ends
+    u64 mask[kNT];                             // parse: the positions of chunk t that start a token
+    u32 fw[288];                               // huff_build's working copy of the counts
+    u8 bcost[256];                             // estimated cost of a literal byte in 1/16 bit, from the block's byte histogram
     u32 hdr[192];                              // the dynamic block header, as bits
     u16 clsym[320];                            // code-length symbols of the header: symbol | extra << 8
     u32 vars[V_N];
@@ -88,6 +95,8 @@ struct DeflateArgs {
     u32* scratch;          // [gridDim.x][65536]: match table, then the tokens
     u32* n_stored;         // counter
     u32 lazy;
+    u32 cost_base, cost_rle;    // estimated bits of a match's length + distance codes (distance 1: cost_rle); 0 = take every match
+    unsigned long long* prof;   // optional [8]: cycles per phase, summed over blocks (MGX_BGZF_PROF=1)
 };
 
 __device__ __forceinline__ u32 load32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
@@ -135,10 +144,31 @@ __device__ __forceinline__ u32 match_len(const u8* a, const u8* b, u32 maxlen) {
     return len;
 }
 
+// Workgroup-wide exclusive prefix sum (wave shuffles, then the wave totals through LDS).  *total = sum of all values.
+__device__ __forceinline__ u32 block_scan(Lds& L, u32 v, u32* total) {
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = __shfl_up(inc, off, 64); if (lane >= (u32)off) inc += o; }
+    __syncthreads();                                   // earlier readers of L.wsum are done
+    if (lane == 63) L.wsum[wave] = inc;
+    __syncthreads();
+    u32 before = 0, all = 0;
+#pragma unroll
+    for (u32 w = 0; w < kNT / 64; ++w) { const u32 t = L.wsum[w]; all += t; if (w < wave) before += t; }
+    *total = all;
+    return before + inc - v;
+}
+
 // Length-limited Huffman code of freq[0, N): lengths and (bit-reversed) canonical codes.  Called by the whole workgroup.
 // At least two symbols get a code (inflate accepts no incomplete literal/length or code-length code).
-__device__ void huff_build(Lds& L, u32* freq, const int N, const int limit, u8* len, u16* code) {
+// Parallel but for the merge itself: ranks by counting, leaf depths by walking up the parent links, code values by
+// counting the earlier symbols of the same length.
+__device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int limit, u8* len, u16* code) {
     const int tid = (int)threadIdx.x;
+    __syncthreads();
+    if (tid < N) L.fw[tid] = freq_in[tid];            // the caller's counts stay as they are (they price the block)
+    u32* const freq = L.fw;
     __syncthreads();
     if (tid == 0) {
         int used = 0;
@@ -148,66 +178,73 @@ __device__ void huff_build(Lds& L, u32* freq, const int N, const int limit, u8* 
     }
     for (;;) {
         __syncthreads();
-        for (int s = tid; s < N; s += kNT) {
-            len[s] = 0;
-            const u32 f = freq[s];
+        if (tid < 16) L.bl_count[tid] = 0;
+        if (tid == 0) { L.vars[V_NUSED] = 0; L.vars[V_OVER] = 0; }
+        __syncthreads();
+        if (tid < N) {
+            len[tid] = 0;
+            const u32 f = freq[tid];
             if (f) {
                 int r = 0;
-                for (int j = 0; j < N; ++j) { const u32 g = freq[j]; r += (g != 0) & ((g < f) | ((g == f) & (j < s))); }
-                L.sorted[r] = (u16)s;
+                for (int j = 0; j < N; ++j) { const u32 g = freq[j]; r += (g != 0) & ((g < f) | ((g == f) & (j < tid))); }
+                L.sorted[r] = (u16)tid;
+                L.wl[r] = f;
+                atomicAdd(&L.vars[V_NUSED], 1u);
             }
         }
         __syncthreads();
+        const int n = (int)L.vars[V_NUSED];
         if (tid == 0) {
-            int n = 0;
-            for (int s = 0; s < N; ++s) n += freq[s] != 0;
-            for (int i = 0; i < n; ++i) L.wl[i] = freq[L.sorted[i]];
+            // two-queue merge: leaves in weight order, internal nodes in creation order.  The heads of both queues are
+            // kept in registers and refilled with loads that do not depend on the step's result.
+            const u32 kInf = 0xFFFFFFFFu;
             int i = 0, j = 0;
-            for (int k = 0; k < n - 1; ++k) {            // two-queue merge: leaves in weight order, internal nodes in creation order
+            u32 la = L.wl[0], lb = n > 1 ? L.wl[1] : kInf, ia = kInf, ib = kInf;
+            for (int k = 0; k < n - 1; ++k) {
                 u32 w2 = 0;
+#pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    int id;
-                    if (i < n && (j >= k || L.wl[i] <= L.wi[j])) { id = i; w2 += L.wl[i]; ++i; }
-                    else { id = n + j; w2 += L.wi[j]; ++j; }
-                    L.parent[id] = (u16)(n + k);
+                    if (la <= ia) {                  // a leaf (ties: the leaf, which keeps the tree shallow)
+                        L.parent[i] = (u16)(n + k); w2 += la; ++i;
+                        la = lb; lb = i + 1 < n ? L.wl[i + 1] : kInf;
+                    } else {
+                        L.parent[n + j] = (u16)(n + k); w2 += ia; ++j;
+                        ia = ib; ib = j + 1 < k ? L.wi[j + 1] : kInf;
+                    }
                 }
                 L.wi[k] = w2;
+                // node k joins the internal queue: it is its head or second entry if the queue is that short
+                if (j == k) ia = w2; else if (j + 1 == k) ib = w2;
             }
-            L.depth[2 * n - 2] = 0;
-            int maxd = 0;
-            for (int id = 2 * n - 3; id >= 0; --id) {
-                const int d = L.depth[L.parent[id]] + 1;
-                L.depth[id] = (u8)d;
-                if (id < n && d > maxd) maxd = d;
-            }
-            if (maxd <= limit) for (int q = 0; q < n; ++q) len[L.sorted[q]] = L.depth[q];
-            L.vars[V_OVER] = maxd > limit;
+        }
+        __syncthreads();
+        if (tid < n) {                               // depth of leaf tid: steps to the root (node 2n - 2)
+            int d = 0;
+            for (int id = tid; id != 2 * n - 2; id = L.parent[id]) ++d;
+            if (d > limit) L.vars[V_OVER] = 1;
+            len[L.sorted[tid]] = (u8)d;
+            atomicAdd(&L.bl_count[d < 16 ? d : 15], 1u);
         }
         __syncthreads();
         if (!L.vars[V_OVER]) break;
-        for (int s = tid; s < N; s += kNT) { const u32 f = freq[s]; if (f) freq[s] = (f + 1) >> 1; }     // flatter, still >= 1
+        if (tid < N) { const u32 f = freq[tid]; if (f) freq[tid] = (f + 1) >> 1; }     // flatter, still >= 1
     }
-    if (tid < 16) {
-        u32 c = 0;
-        for (int s = 0; s < N; ++s) c += (len[s] == tid);
-        L.bl_count[tid] = tid ? c : 0;
-    }
-    __syncthreads();
     if (tid == 0) {
         u32 c = 0;
         L.next_code[0] = 0;
+        L.bl_count[0] = 0;
         for (int bits = 1; bits <= 15; ++bits) { c = (c + L.bl_count[bits - 1]) << 1; L.next_code[bits] = c; }
     }
     __syncthreads();
-    for (int s = tid; s < N; s += kNT) {
-        const u32 l = len[s];
+    if (tid < N) {
+        const u32 l = len[tid];
         u32 c = 0;
         if (l) {
             c = L.next_code[l];
-            for (int j = 0; j < s; ++j) c += (len[j] == l);
+            for (int j = 0; j < tid; ++j) c += (len[j] == l);
             c = __brev(c) >> (32 - l);
         }
-        code[s] = (u16)c;
+        code[tid] = (u16)c;
     }
     __syncthreads();
 }
@@ -223,11 +260,24 @@ struct BitSink {          // LSB-first bit writer into 32-bit words shared with 
     __device__ __forceinline__ void finish() { if (nbits) atomicOr(&words[word], (u32)acc); }
 };
 
+// A token in 32 bits: bits 0..8 literal/length symbol (kTokNone: the position starts no token), 9..13 the length's
+// extra value, 14..18 the distance symbol, 19..31 the distance's extra value.
+constexpr u32 kTokNone = 0x1FFu;
+__device__ __forceinline__ u32 length_extra_bits(u32 ls) { return (ls >= 265 && ls < 285) ? (ls - 261) >> 2 : 0u; }
+__device__ __forceinline__ u32 dist_extra_bits(u32 ds) { return ds >= 4 ? (ds >> 1) - 1 : 0u; }
+__device__ __forceinline__ u32 token_bits(const Lds& L, u32 tok) {
+    const u32 ls = tok & 0x1FFu;
+    if (ls == kTokNone) return 0;
+    u32 nb = L.l_ll[ls];
+    if (ls > 256) { const u32 ds = (tok >> 14) & 31u; nb += length_extra_bits(ls) + L.l_d[ds] + dist_extra_bits(ds); }
+    return nb;
+}
+
 __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     Lds& L = *reinterpret_cast<Lds*>(smem);
     const u32 tid = threadIdx.x;
-    u32* const mat = a.scratch + (size_t)blockIdx.x * 65536u;
+    u32* const mat = a.scratch + (size_t)blockIdx.x * kScratchPerWg;
 
     for (u32 i = tid; i < 256; i += kNT) {
         u32 c = i;
@@ -246,6 +296,8 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         const u32 n = (u32)(a.off[blk + 1] - o0);
         const u32 mis = (u32)(o0 & 3u);
         u8* const in = reinterpret_cast<u8*>(L.buf) + mis;           // the LDS copy keeps the source's word alignment
+        long long t_prev = a.prof ? clock64() : 0;
+        auto lap = [&](int k) { if (a.prof && tid == 0) { const long long t = clock64(); atomicAdd(&a.prof[k], (unsigned long long)(t - t_prev)); t_prev = t; } };
         // ---- load (whole words; the bytes around the block are another block's or padding)
         {
             const u32* src = reinterpret_cast<const u32*>(a.in + (o0 - mis));
@@ -258,87 +310,165 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         if (tid < 20) L.f_cl[tid] = 0;
         __syncthreads();
         for (u32 i = tid; i < kPad; i += kNT) in[n + i] = 0;
+        // byte histogram -> what a literal costs (a match is only worth taking if it beats the literals it replaces:
+        // in quality strings of a few distinct values a literal costs 1-2 bits and a short match 15-25)
+        // (every fourth byte is sample enough for an estimate)
+        for (u32 i = tid * 4u + ((tid >> 8) & 3u); i < n; i += kNT * 4u) atomicAdd(&L.f_ll[in[i]], 1u);
         __syncthreads();
+        if (tid < 256) {
+            const u32 f = L.f_ll[tid];
+            const float bits = f ? 16.0f * __log2f((float)((n + 3) >> 2) / (float)f) : 255.0f;
+            L.bcost[tid] = (u8)min(255.0f, bits + 0.5f);
+        }
+        __syncthreads();
+        if (tid < 256) L.f_ll[tid] = 0;
+        lap(0);
 
-        // ---- 1. match search
-        for (u32 base = 0; base < n; base += kNT) {
+        // ---- 1. match search.  Wavefront 0 walks the hash table for the NEXT window, 64 positions per step: the LDS
+        //         executes a wavefront's instructions in order, so a step's lookups see every earlier step's entries and
+        //         none of its own -- candidates are blind to the last < 64 bytes only, and the outcome is deterministic.
+        auto produce = [&](u32 base, u16* cb) {
+#pragma unroll
+            for (int k = 0; k < kNT / 64; ++k) {
+                const u32 p = base + (u32)k * 64u + tid;
+                u32 c = 0;
+                if (p + 4 <= n) {
+                    const u32 h = (load32(in + p) * 2654435761u) >> (32 - kHashBits);
+                    c = L.head[h];
+                    atomicMax(&L.head[h], p + 1);
+                }
+                cb[k * 64 + (int)tid] = (u16)c;
+            }
+        };
+        __syncthreads();
+        if (tid < 64) produce(0, L.cand[0]);
+        __syncthreads();
+        for (u32 w = 0, base = 0; base < n; ++w, base += kNT) {
+            if (tid < 64 && base + kNT < n) produce(base + kNT, L.cand[(w + 1) & 1]);
             const u32 p = base + tid;
-            const bool hashed = p + 4 <= n;
-            u32 h = 0, cand = 0;
-            if (hashed) { h = (load32(in + p) * 2654435761u) >> (32 - kHashBits); cand = L.head[h]; }
-            __syncthreads();
-            if (hashed) atomicMax(&L.head[h], p + 1);
+            u32 len = 0, dist = 0;
             if (p < n) {
                 const u32 maxlen = min(258u, n - p);
-                u32 best_len = 0, best_dist = 0;
+                const u32 cand = L.cand[w & 1][tid];
                 if (cand) {
-                    const u32 q = cand - 1, dist = p - q;
-                    if (dist <= 32768u) {
-                        const u32 len = match_len(in + q, in + p, maxlen);
-                        if (len >= 4) { best_len = len; best_dist = dist; }
+                    const u32 q = cand - 1, d = p - q;
+                    if (d <= 32768u) {
+                        const u32 l = match_len(in + q, in + p, maxlen);
+                        if (l >= 4) { len = l; dist = d; }
                     }
                 }
                 if (p >= 1 && maxlen >= 3 && in[p - 1] == in[p]) {
-                    const u32 len = match_len(in + p - 1, in + p, maxlen);
-                    if (len >= 3 && len >= best_len) { best_len = len; best_dist = 1; }
+                    const u32 l = match_len(in + p - 1, in + p, maxlen);
+                    if (l >= 3 && l >= len) { len = l; dist = 1; }
                 }
-                mat[p] = best_len ? (best_len << 16 | best_dist) : 0u;
+                if (len && len <= 16 && a.cost_base) {
+                    // the literals a short match replaces, priced from its first four bytes (three for a 3-byte match)
+                    const u32 w4 = load32(in + p);
+                    u32 lit = (u32)L.bcost[w4 & 0xffu] + L.bcost[(w4 >> 8) & 0xffu] + L.bcost[(w4 >> 16) & 0xffu];
+                    lit = len == 3 ? lit : (lit + L.bcost[w4 >> 24]) * len >> 2;
+                    const u32 x = dist - 1;
+                    const u32 extra = x < 4 ? 0 : (31 - __builtin_clz(x)) - 1;
+                    if (16u * ((dist == 1 ? a.cost_rle : a.cost_base) + extra) >= lit) len = 0;
+                }
             }
+            // one-step lazy evaluation: a longer match starting at the next byte (the neighbouring lane's) wins; the decision
+            // is a function of the position alone, whatever the parse does around it
+            const u32 len_next = __shfl_down(len, 1, 64);
+            if (a.lazy && (tid & 63u) != 63u && len_next > len) len = 0;
+            mat[p] = len ? (len << 16 | dist) : 0u;
             __syncthreads();
         }
+        lap(1);
 
-        // ---- 2. parse: thread t owns bytes [lo, hi)
-        const u32 chunk = (n + kNT - 1) / kNT;
-        const u32 lo = min(n, tid * chunk), hi = min(n, lo + chunk);
-        u32 n_tok = 0;
+        // ---- 2. parse.  The token at a position is fixed (above); which positions START a token is the chain
+        //         0 -> 0 + len(0) -> ...  Thread t walks the 64 positions of chunk t in registers from the position the
+        //         previous chunk's last token ends at; that end depends on where the previous chunk started, so the
+        //         walk is repeated until no chunk's start moves (two or three rounds on BAM bytes, at most one per chunk).
+        const u32 lo = tid * 64u;
+        const u32 cl = lo < n ? min(64u, n - lo) : 0u;
+        u32 m[64];
         {
-            u32 p = lo;
-            while (p < hi) {
-                const u32 m = mat[p];
-                u32 len = min(m >> 16, hi - p), dist = m & 0xffffu;
-                if (len < 3) len = 0;
-                if (len && a.lazy && p + 1 < hi) {
-                    const u32 len2 = min(mat[p + 1] >> 16, hi - p - 1);
-                    if (len2 > len) len = 0;                          // a longer match starts one byte on: literal now
-                }
-                u32 tok;
-                if (len) {
-                    u32 ls, leb, lev, ds, deb, dev;
-                    length_code(len, &ls, &leb, &lev);
-                    dist_code(dist, &ds, &deb, &dev);
-                    atomicAdd(&L.f_ll[ls], 1u);
-                    atomicAdd(&L.f_d[ds], 1u);
-                    tok = 0x80000000u | (len - 3) << 16 | (dist - 1);
-                    p += len;
-                } else {
-                    tok = in[p];
-                    atomicAdd(&L.f_ll[tok], 1u);
-                    p += 1;
-                }
-                mat[lo + n_tok++] = tok;        // in place: token k of this thread lies at or before the byte it starts at
+            const uint4* v = reinterpret_cast<const uint4*>(mat + lo);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint4 x = v[q];
+                m[4 * q] = x.x >> 16; m[4 * q + 1] = x.y >> 16; m[4 * q + 2] = x.z >> 16; m[4 * q + 3] = x.w >> 16;
             }
         }
-        // ---- 5. CRC-32 of the piece, shifted to the end of the block
-        u32 crc_part;
+        auto walk = [&](u32 start) -> u32 {                 // chunk-relative; returns where the last token ends (may pass 64)
+            u32 next = start;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) next += m[i] ? m[i] : 1u;
+            return next;
+        };
+        u32 cur_start = lo;
+        u32 my_end = cl ? lo + walk(0) : lo;
+        L.cend[tid] = my_end;
+        for (;;) {
+            __syncthreads();
+            const u32 prev = tid ? L.cend[tid - 1] : 0u;
+            const u32 st = max(lo, prev);
+            const bool changed = st != cur_start;
+            if (changed) { cur_start = st; my_end = (st >= lo + cl) ? st : lo + walk(st - lo); }
+            const int any = __syncthreads_or((int)changed);
+            if (changed) L.cend[tid] = my_end;
+            if (!any) break;
+        }
+        {
+            u64 mask = 0;
+            u32 next = cur_start - lo;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) { mask |= 1ull << i; next += m[i] ? m[i] : 1u; }
+            L.mask[tid] = mask;
+        }
+        // ---- 5. CRC-32 of the chunk, shifted to the end of the block
         {
             u32 c = tid == 0 ? 0xFFFFFFFFu : 0u;
-            for (u32 p = lo; p < hi; ++p) c = L.crc_tab[(c ^ in[p]) & 0xffu] ^ (c >> 8);
-            u32 e = 8u * (n - hi), xp = 0x80000000u;
+            for (u32 p = lo; p < lo + cl; ++p) c = L.crc_tab[(c ^ in[p]) & 0xffu] ^ (c >> 8);
+            u32 e = 8u * (n - (lo + cl)), xp = 0x80000000u;
+            if (lo >= n) e = 0;
             for (int k = 0; e; ++k, e >>= 1) if (e & 1u) xp = multmodp(L.x2n[k], xp);
-            crc_part = multmodp(xp, c);
+            u32 part = multmodp(xp, c);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) part ^= __shfl_xor(part, off, 64);
+            if ((tid & 63u) == 0) L.wsum[tid >> 6] = part;
         }
-        L.scan[tid] = crc_part;
         if (tid == 0) L.f_ll[256] = 1;             // end of block
         __syncthreads();
         if (tid == 0) {
             u32 c = 0;
-            for (int i = 0; i < kNT; ++i) c ^= L.scan[i];
+            for (int i = 0; i < kNT / 64; ++i) c ^= L.wsum[i];
             L.vars[V_CRC] = c ^ 0xFFFFFFFFu;
         }
+        lap(2);
+        // ---- tokens, position-parallel: the position's token in packed form, and the symbol counts
+        for (u32 base = 0; base < n; base += kNT) {
+            const u32 p = base + tid;
+            u32 tok = kTokNone;
+            if (p < n && ((L.mask[p >> 6] >> (p & 63u)) & 1ull)) {
+                const u32 mm = mat[p];
+                const u32 len = mm >> 16;
+                if (len) {
+                    u32 ls, leb, lev, ds, deb, dev;
+                    length_code(len, &ls, &leb, &lev);
+                    dist_code(mm & 0xffffu, &ds, &deb, &dev);
+                    atomicAdd(&L.f_ll[ls], 1u);
+                    atomicAdd(&L.f_d[ds], 1u);
+                    tok = ls | lev << 9 | ds << 14 | dev << 19;
+                } else {
+                    tok = in[p];
+                    atomicAdd(&L.f_ll[tok], 1u);
+                }
+            }
+            mat[p] = tok;
+        }
+        __syncthreads();
+        lap(3);
 
         // ---- 3. codes
         huff_build(L, L.f_ll, kNumLL, 15, L.l_ll, L.c_ll);
         huff_build(L, L.f_d, kNumD, 15, L.l_d, L.c_d);
+        lap(4);
         if (tid == 0) {
             int nlit = kNumLL, ndist = kNumD;
             while (nlit > 257 && L.l_ll[nlit - 1] == 0) --nlit;
@@ -394,59 +524,50 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             if (nbits) L.hdr[word] = (u32)acc;
         }
         __syncthreads();
+        lap(5);
 
-        // ---- 4. measure, scan, emit
-        u32 my_bits = 0;
-        for (u32 k = 0; k < n_tok; ++k) {
-            const u32 tok = mat[lo + k];
-            if (tok & 0x80000000u) {
-                u32 ls, leb, lev, ds, deb, dev;
-                length_code(((tok >> 16) & 0xffu) + 3, &ls, &leb, &lev);
-                dist_code((tok & 0xffffu) + 1, &ds, &deb, &dev);
-                my_bits += L.l_ll[ls] + leb + L.l_d[ds] + deb;
-            } else {
-                my_bits += L.l_ll[tok];
-            }
-        }
-        L.scan[tid] = my_bits;
-        __syncthreads();
-        for (u32 off = 1; off < kNT; off <<= 1) {
-            const u32 v = tid >= off ? L.scan[tid - off] : 0;
-            __syncthreads();
-            L.scan[tid] += v;
-            __syncthreads();
-        }
+        // ---- 4. size (from the symbol counts), then the bits, position-parallel
+        u32 sym_bits = 0;
+        if (tid < (u32)kNumLL) sym_bits = L.f_ll[tid] * (L.l_ll[tid] + (tid > 256 ? length_extra_bits(tid) : 0u));
+        else if (tid >= 512 && tid < 512u + kNumD) sym_bits = L.f_d[tid - 512] * (L.l_d[tid - 512] + dist_extra_bits(tid - 512));
+        u32 token_total;
+        (void)block_scan(L, sym_bits, &token_total);          // includes the end-of-block symbol
         const u32 hdr_bits = L.vars[V_HDRBITS];
-        const u32 total_bits = hdr_bits + L.scan[kNT - 1] + L.l_ll[256];
-        const u32 my_start = hdr_bits + L.scan[tid] - my_bits;
+        const u32 total_bits = hdr_bits + token_total;
         u32 payload = (total_bits + 7) >> 3;
         const bool stored = payload >= n + 5 || n == 0;
         u8* const slot = a.slots + (size_t)blk * kSlot + kSlotSkew;
         u8* const pay = slot + 18;
-        __syncthreads();                                    // every reader of the input bytes and of scan[] is done
+        __syncthreads();                                    // every reader of the input bytes is done
         if (!stored) {
             const u32 nw = (payload + 3) >> 2;
             for (u32 w = tid; w < nw; w += kNT) L.buf[w] = 0;
             __syncthreads();
             for (u32 w = tid; w < ((hdr_bits + 31) >> 5); w += kNT) atomicOr(&L.buf[w], L.hdr[w]);
-            BitSink s;
-            s.start(L.buf, my_start);
-            for (u32 k = 0; k < n_tok; ++k) {
-                const u32 tok = mat[lo + k];
-                if (tok & 0x80000000u) {
-                    u32 ls, leb, lev, ds, deb, dev;
-                    length_code(((tok >> 16) & 0xffu) + 3, &ls, &leb, &lev);
-                    dist_code((tok & 0xffffu) + 1, &ds, &deb, &dev);
+            u32 carry = hdr_bits;
+            u32 nxt = mat[tid];
+            for (u32 base = 0; base < n; base += kNT) {
+                const u32 tok = nxt;
+                if (base + kNT < n) nxt = mat[base + kNT + tid];
+                const u32 nb = token_bits(L, tok);
+                u32 window_bits;
+                const u32 off = block_scan(L, nb, &window_bits);
+                if (nb) {
+                    BitSink s;
+                    s.start(L.buf, carry + off);
+                    const u32 ls = tok & 0x1FFu;
                     s.put(L.c_ll[ls], L.l_ll[ls]);
-                    if (leb) s.put(lev, leb);
-                    s.put(L.c_d[ds], L.l_d[ds]);
-                    if (deb) s.put(dev, deb);
-                } else {
-                    s.put(L.c_ll[tok], L.l_ll[tok]);
+                    if (ls > 256) {
+                        const u32 ds = (tok >> 14) & 31u, leb = length_extra_bits(ls), deb = dist_extra_bits(ds);
+                        if (leb) s.put((tok >> 9) & 31u, leb);
+                        s.put(L.c_d[ds], L.l_d[ds]);
+                        if (deb) s.put(tok >> 19, deb);
+                    }
+                    s.finish();
                 }
+                carry += window_bits;
             }
-            if (tid == kNT - 1) s.put(L.c_ll[256], L.l_ll[256]);
-            s.finish();
+            if (tid == 0) { BitSink s; s.start(L.buf, carry); s.put(L.c_ll[256], L.l_ll[256]); s.finish(); }
             __syncthreads();
             u32* payw = reinterpret_cast<u32*>(pay);
             for (u32 w = tid; w < (payload >> 2); w += kNT) payw[w] = L.buf[w];
@@ -473,6 +594,7 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             a.sizes[blk] = total;
         }
         __syncthreads();                                    // LDS is reused by the next block
+        lap(6);
     }
 }
 
@@ -517,7 +639,8 @@ struct mgx_bgzf {
     hipStream_t stream = nullptr;              // all batches of a context run in order on one stream
     u32* d_scratch = nullptr; u32 grid = 0;
     u32* d_n_stored = nullptr;
-    u32 lazy = 1;
+    unsigned long long* d_prof = nullptr;
+    u32 lazy = 1, cost_base = 10, cost_rle = 6;
     u64 n_blocks = 0, bytes_in = 0, bytes_out = 0;
     float ms_kernels = 0;
 };
@@ -553,12 +676,18 @@ int mgx_bgzf_create(int device, unsigned flags, mgx_bgzf_t** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lazy = (flags & 1u) ? 0 : 1;
     if (const char* e = getenv("MGX_BGZF_LAZY")) c->lazy = atoi(e) != 0;
+    if (const char* e = getenv("MGX_BGZF_COST_BASE")) c->cost_base = (u32)atoi(e);
+    if (const char* e = getenv("MGX_BGZF_COST_RLE")) c->cost_rle = (u32)atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->grid = (u32)c->n_cu;                       // ~94 KB of LDS per workgroup: one per CU
     if (const char* e = getenv("MGX_BGZF_GRID")) { const int v = atoi(e); if (v > 0) c->grid = (u32)v; }
-    HIP_TRY(hipMalloc((void**)&c->d_scratch, (size_t)c->grid * 65536u * sizeof(u32)));
+    HIP_TRY(hipMalloc((void**)&c->d_scratch, (size_t)c->grid * kScratchPerWg * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->d_n_stored, sizeof(u32)));
     HIP_TRY(hipMemset(c->d_n_stored, 0, sizeof(u32)));
+    if (const char* e = getenv("MGX_BGZF_PROF")) if (atoi(e)) {
+        HIP_TRY(hipMalloc((void**)&c->d_prof, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_prof, 0, 8 * sizeof(unsigned long long)));
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)k_bgzf_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
     *out = c.release();
     return 0;
@@ -570,6 +699,13 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     (void)hipFree(c->d_scratch);
     (void)hipFree(c->d_n_stored);
+    if (c->d_prof) {
+        unsigned long long p[8];
+        if (hipMemcpy(p, c->d_prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess && c->n_blocks)
+            fprintf(stderr, "mgx_bgzf cycles per block: load %llu, match %llu, parse+crc %llu, tokens %llu, huffman %llu, header %llu, emit %llu\n", p[0] / c->n_blocks,
+                    p[1] / c->n_blocks, p[2] / c->n_blocks, p[3] / c->n_blocks, p[4] / c->n_blocks, p[5] / c->n_blocks, p[6] / c->n_blocks);
+        (void)hipFree(c->d_prof);
+    }
     delete c;
 }
 
@@ -635,7 +771,7 @@ int mgx_bgzf_batch_submit(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, uint32_t n_blocks)
     HIP_TRY(hipMemcpyAsync(b->d_off, b->h_off, ((size_t)n_blocks + 1) * sizeof(u64), hipMemcpyHostToDevice, s));
     DeflateArgs a{};
     a.in = b->d_in; a.off = b->d_off; a.n_blocks = n_blocks; a.slots = b->d_slots; a.sizes = b->d_sizes;
-    a.scratch = c->d_scratch; a.n_stored = c->d_n_stored; a.lazy = c->lazy;
+    a.scratch = c->d_scratch; a.n_stored = c->d_n_stored; a.lazy = c->lazy; a.cost_base = c->cost_base; a.cost_rle = c->cost_rle; a.prof = c->d_prof;
     HIP_TRY(hipEventRecord(b->ev_k0, s));
     hipLaunchKernelGGL(k_bgzf_deflate, dim3(std::min(c->grid, n_blocks)), dim3(kNT), sizeof(Lds), s, a);
     hipLaunchKernelGGL(k_bgzf_offsets, dim3(1), dim3(256), 0, s, b->d_sizes, n_blocks, b->d_out_off);
