@@ -1,6 +1,8 @@
 // bam_writer.cpp -- see bam_writer.h.  Formats follow SAMv1 sections 4.1 (BGZF), 4.2 (BAM), 5.2 (BAI).
 #include "bam_writer.h"
 
+#include "../../../include/mgx_bgzf.h"
+
 #include <zlib.h>
 
 #include <algorithm>
@@ -18,6 +20,7 @@ namespace {
 
 constexpr size_t kBlockIn = 0xff00;          // uncompressed bytes per BGZF block
 constexpr size_t kBgzfHeader = 18, kBgzfFooter = 8;
+constexpr uint32_t kDeviceBatchBlocks = 512;   // BGZF blocks per device batch (32 MB of BAM bytes), two batches per writer thread
 
 template <typename T>
 inline void put(std::vector<uint8_t>& a, T v) { const uint8_t* p = (const uint8_t*)&v; a.insert(a.end(), p, p + sizeof(T)); }
@@ -101,6 +104,97 @@ void compress_slice(const std::vector<RecordRef>& recs, size_t lo, size_t hi, De
     flush();
 }
 
+// The same slice through the device compressor (mgx_bgzf.h): the records are gathered straight into a batch's pinned
+// input buffer, block boundaries are only offsets into it, and two batches per writer thread alternate (one being
+// filled while the other is on the device).  Virtual offsets are kept as (block ordinal << 16 | offset in block)
+// until the compressed position of every block is known.
+struct DeviceSlice {
+    mgx_bgzf_t* ctx = nullptr;
+    mgx_bgzf_batch_t* batch[2] = {nullptr, nullptr};
+    uint64_t cap = 0; uint32_t max_blocks = 0;
+    std::string err;
+    bool create(int device, uint64_t capacity, uint32_t blocks) {
+        cap = capacity; max_blocks = blocks;
+        if (mgx_bgzf_create(device, 0, &ctx)) { err = mgx_last_error(); return false; }
+        for (int i = 0; i < 2; ++i)
+            if (mgx_bgzf_batch_create(ctx, cap, max_blocks, &batch[i])) { err = mgx_last_error(); return false; }
+        return true;
+    }
+    ~DeviceSlice() {
+        for (int i = 0; i < 2; ++i) if (batch[i]) mgx_bgzf_batch_destroy(ctx, batch[i]);
+        if (ctx) mgx_bgzf_destroy(ctx);
+    }
+};
+
+void compress_slice_device(const std::vector<RecordRef>& recs, size_t lo, size_t hi, DeviceSlice* dv, Slice* s) {
+    s->vbeg.resize(hi - lo); s->vend.resize(hi - lo);
+    std::vector<uint64_t> block_at;            // compressed offset of block k of the slice; one more entry = slice length
+    int cur = 0;                               // batch being filled
+    uint32_t in_flight[2] = {0, 0};            // blocks submitted and not yet collected
+    uint8_t* in = mgx_bgzf_batch_input(dv->batch[cur]);
+    uint64_t* off = mgx_bgzf_batch_offsets(dv->batch[cur]);
+    uint32_t nb = 0;                           // closed blocks of the current batch
+    uint64_t fill = 0;                         // bytes in the current batch; the open block is [off[nb], fill)
+    uint64_t ordinal = 0;                      // blocks closed so far in the slice
+    off[0] = 0;
+    auto collect = [&](int k) {
+        if (!in_flight[k]) return;
+        const uint8_t* o; const uint64_t* oo;
+        if (mgx_bgzf_batch_wait(dv->ctx, dv->batch[k], &o, &oo)) { s->ok = false; dv->err = mgx_last_error(); in_flight[k] = 0; return; }
+        const uint64_t base = s->bytes.size();
+        for (uint32_t i = 0; i < in_flight[k]; ++i) block_at.push_back(base + oo[i]);
+        s->bytes.insert(s->bytes.end(), o, o + oo[in_flight[k]]);
+        in_flight[k] = 0;
+    };
+    auto submit = [&]() {                      // sends the closed blocks of the current batch, moves on to the other one
+        if (nb == 0) return;
+        collect(cur ^ 1);                      // keeps the slice's blocks in order: the older batch first
+        if (mgx_bgzf_batch_submit(dv->ctx, dv->batch[cur], nb)) { s->ok = false; dv->err = mgx_last_error(); }
+        else in_flight[cur] = nb;
+        // the open block's bytes move to the head of the other batch
+        const uint64_t open0 = off[nb], open_n = fill - open0;
+        uint8_t* in2 = mgx_bgzf_batch_input(dv->batch[cur ^ 1]);
+        if (open_n) memcpy(in2, in + open0, open_n);
+        cur ^= 1;
+        in = in2; off = mgx_bgzf_batch_offsets(dv->batch[cur]);
+        off[0] = 0; nb = 0; fill = open_n;
+    };
+    auto close_block = [&](uint64_t at) {      // the open block ends at byte `at` of the batch
+        off[++nb] = at;
+        ++ordinal;
+    };
+    for (size_t k = lo; k < hi && s->ok; ++k) {
+        const RecordRef& r = recs[k];
+        const uint64_t need = 4 + (uint64_t)r.len;
+        if (fill - off[nb] > 0 && fill - off[nb] + need > kBlockIn) close_block(fill);
+        // room for the record and for the blocks it may close
+        if (fill + need > dv->cap || nb + need / kBlockIn + 2 > dv->max_blocks) {
+            if (fill > off[nb] && fill + need > dv->cap && nb == 0) close_block(fill);   // a batch of one short block rather than none
+            submit();
+            if (fill + need > dv->cap) { s->ok = false; dv->err = "a record larger than the compressor's batch"; break; }
+        }
+        s->vbeg[k - lo] = (ordinal << 16) | (fill - off[nb]);
+        const uint32_t bs = r.len;
+        memcpy(in + fill, &bs, 4);
+        memcpy(in + fill + 4, r.blob, r.len);
+        if (r.set_dup) { uint16_t f; memcpy(&f, in + fill + 4 + kFlagOffset, 2); f |= 0x400; memcpy(in + fill + 4 + kFlagOffset, &f, 2); }
+        fill += need;
+        while (fill - off[nb] > kBlockIn) close_block(off[nb] + kBlockIn);      // a record larger than one block spans several
+        if (fill - off[nb] == kBlockIn) close_block(fill);
+        s->vend[k - lo] = (ordinal << 16) | (fill - off[nb]);
+    }
+    if (fill > off[nb]) close_block(fill);
+    submit();
+    collect(cur);          // (the batch just left is cur ^ 1 after submit's swap; both are collected, older first)
+    collect(cur ^ 1);
+    block_at.push_back(s->bytes.size());
+    if (s->ok)
+        for (size_t i = 0; i < s->vbeg.size(); ++i) {
+            s->vbeg[i] = (block_at[s->vbeg[i] >> 16] << 16) | (s->vbeg[i] & 0xffff);
+            s->vend[i] = (block_at[s->vend[i] >> 16] << 16) | (s->vend[i] & 0xffff);
+        }
+}
+
 inline uint64_t rebase(uint64_t v, uint64_t base) { return (((v >> 16) + base) << 16) | (v & 0xffff); }
 
 struct RefIndex {
@@ -143,7 +237,7 @@ void encode_record(const samtext::Record& r, std::vector<uint8_t>* out) {
 }
 
 bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
-               int threads, int level, std::string* err) {
+               int threads, int level, int device, std::string* err) {
     // ---- BAM header, in BGZF blocks of its own
     std::vector<uint8_t> head;
     head.insert(head.end(), {'B', 'A', 'M', 1});
@@ -157,7 +251,19 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
         put<int32_t>(head, (int32_t)hdr.ref_len[i]);
     }
     std::vector<uint8_t> file;
-    {
+    if (device >= 0) {
+        mgx_bgzf_t* ctx = nullptr;
+        if (mgx_bgzf_create(device, 0, &ctx)) { *err = mgx_last_error(); return false; }
+        std::vector<uint64_t> off;
+        for (size_t o = 0; o < head.size(); o += kBlockIn) off.push_back(o);
+        off.push_back(head.size());
+        std::vector<uint64_t> out_off(off.size());
+        file.resize(mgx_bgzf_bound(head.size(), off.size() - 1));
+        const int rc = mgx_bgzf_compress(ctx, head.data(), off.data(), off.size() - 1, file.data(), file.size(), out_off.data());
+        mgx_bgzf_destroy(ctx);
+        if (rc) { *err = mgx_last_error(); return false; }
+        file.resize(out_off.back());
+    } else {
         Deflater df(level);
         for (size_t off = 0; off < head.size(); off += kBlockIn)
             if (!bgzf_block(head.data() + off, std::min(kBlockIn, head.size() - off), &df, &file)) { *err = "deflate failed"; return false; }
@@ -166,7 +272,8 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
 
     // ---- records: contiguous slices compressed independently (sortmardup/main.cpp:371-421)
     const size_t n = recs.size();
-    const int T = std::max(1, threads);
+    // device compressor: the writer threads only gather records into pinned memory, a few of them saturate it
+    const int T = device >= 0 ? std::max(1, std::min(threads, 8)) : std::max(1, threads);
     const size_t n_slices = n ? std::min<size_t>((size_t)T * 4, (n + 4095) / 4096) : 0;
     std::vector<Slice> slices(n_slices);
     std::vector<size_t> lo(n_slices + 1, 0);
@@ -177,19 +284,34 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
     if (!f) { *err = "cannot open " + path; return false; }
     bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
     std::vector<uint64_t> base(n_slices + 1, header_end);
+    std::string dev_err_copy;
     {
         std::vector<std::thread> pool;
         size_t next = 0;
         std::mutex mu;
         std::condition_variable cv;
         std::vector<char> done(n_slices, 0);
+        std::string dev_err;
         for (int t = 0; t < T; ++t)
             pool.emplace_back([&]() {
-                Deflater df(level);
+                std::unique_ptr<Deflater> df;
+                std::unique_ptr<DeviceSlice> dv;
+                bool dev_ok = true;
+                if (device >= 0) {
+                    dv.reset(new DeviceSlice);
+                    dev_ok = dv->create(device, (uint64_t)kDeviceBatchBlocks * kBlockIn, kDeviceBatchBlocks);
+                } else {
+                    df.reset(new Deflater(level));
+                }
                 for (;;) {
                     size_t s;
                     { std::lock_guard<std::mutex> g(mu); if (next >= n_slices) return; s = next++; }
-                    compress_slice(recs, lo[s], lo[s + 1], &df, &slices[s]);
+                    if (device >= 0) {
+                        if (dev_ok) compress_slice_device(recs, lo[s], lo[s + 1], dv.get(), &slices[s]); else slices[s].ok = false;
+                        if (!slices[s].ok) { std::lock_guard<std::mutex> g(mu); if (dev_err.empty()) dev_err = dv->err; }
+                    } else {
+                        compress_slice(recs, lo[s], lo[s + 1], df.get(), &slices[s]);
+                    }
                     { std::lock_guard<std::mutex> g(mu); done[s] = 1; }
                     cv.notify_all();
                 }
@@ -201,9 +323,10 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
             std::vector<uint8_t>().swap(slices[s].bytes);
         }
         for (auto& th : pool) th.join();
+        dev_err_copy = dev_err;
     }
     for (size_t s = 0; s < n_slices; ++s)
-        if (!slices[s].ok) { fclose(f); *err = "deflate failed"; return false; }
+        if (!slices[s].ok) { fclose(f); *err = device >= 0 ? "device compressor: " + dev_err_copy : std::string("deflate failed"); return false; }
     static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     ok = ok && fwrite(eof_block, 1, 28, f) == 28;
     ok = (fclose(f) == 0) && ok;

@@ -29,7 +29,9 @@ struct RecordRef {              // one record of the output, in output order
 };
 
 // Writes <path> and <path>.bai.  Returns false and sets *err on I/O failure.
+// device >= 0: the BGZF blocks are compressed on that HIP device (include/mgx_bgzf.h), the writer threads only gather
+// the records; device < 0: zlib at `level` on the writer threads (the reference's way, bgzf.c:610).
 bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
-               int threads, int level, std::string* err);
+               int threads, int level, int device, std::string* err);
 
 }  // namespace bamout

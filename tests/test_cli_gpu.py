@@ -135,15 +135,16 @@ def reg2bin(beg, end):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_templates,threads,slice_bytes,stdin", [(1200, 4, 0, False), (150, 1, 0, False), (1200, 3, 4096, False), (600, 2, 1500, True)])
-def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads, slice_bytes, stdin):
+@pytest.mark.parametrize("n_templates,threads,slice_bytes,stdin,deflate", [(1200, 4, 0, False, "device"), (150, 1, 0, False, "device"), (1200, 3, 4096, False, "zlib"),
+                                                                          (600, 2, 1500, True, "device"), (9000, 5, 0, False, "device")])
+def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads, slice_bytes, stdin, deflate):
     """slice_bytes > 0 forces the streaming ingest to cut the text into many slices (each ending on a queryname-group
     boundary) that are parsed out of order and committed in order; the result must not depend on it."""
     raw = synth.gen_sortdedup_raw(n_templates, 41 + n_templates, n_contigs=3, contig_len=120000, dup_rate=0.3)
     sam, bam = str(tmp_path / "in.sam"), str(tmp_path / "out.bam")
     header, names, recs = make_sam(raw, sam)
     open(bam, "w").write("stale")                            # the tool must replace an existing file
-    cmd = [build_cli(), "-O", bam, "-t", str(threads)] + (["-s", str(slice_bytes)] if slice_bytes else [])
+    cmd = [build_cli(), "-O", bam, "-t", str(threads), "-z", deflate] + (["-s", str(slice_bytes)] if slice_bytes else [])
     if stdin:
         res = subprocess.run(cmd, stdin=open(sam, "rb"), capture_output=True, text=True)
     else:
@@ -204,6 +205,26 @@ def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads, slice_
     n_no_coor, = struct.unpack_from("<Q", bai, p)
     assert n_no_coor == sum(1 for r in recs if r["tid"] < 0)
     assert indexed == sum(1 for r in recs if r["tid"] >= 0)
+
+
+@pytest.mark.gpu
+def test_cli_device_and_zlib_deflate_hold_the_same_stream(tmp_path, synth):
+    """-z device (BGZF blocks compressed on the MI355X) and -z zlib (the reference's way) differ in the compressed
+    bytes only: the uncompressed BAM stream is the same, byte for byte, and so is the index once virtual offsets are
+    mapped to uncompressed positions."""
+    raw = synth.gen_sortdedup_raw(6000, 77, n_contigs=4, contig_len=300000, dup_rate=0.2)
+    sam = str(tmp_path / "in.sam")
+    make_sam(raw, sam)
+    streams, sizes = [], []
+    for z in ("device", "zlib"):
+        bam = str(tmp_path / f"{z}.bam")
+        res = subprocess.run([build_cli(), "-I", sam, "-O", bam, "-t", "4", "-z", z], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        streams.append(gzip.decompress(open(bam, "rb").read()))
+        sizes.append(os.path.getsize(bam))
+        assert open(bam, "rb").read()[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    assert streams[0] == streams[1]
+    assert sizes[0] < 1.25 * sizes[1]
 
 
 def test_cli_usage_and_build(pkg):
