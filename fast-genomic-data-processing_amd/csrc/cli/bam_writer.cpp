@@ -3,9 +3,15 @@
 
 #include "../../../include/mgx_bgzf.h"
 
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <condition_variable>
@@ -238,6 +244,11 @@ void encode_record(const samtext::Record& r, std::vector<uint8_t>* out) {
 
 bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
                int threads, int level, int device, std::string* err) {
+    const bool trace = getenv("MGX_CLI_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace) fprintf(stderr, "  write_bam %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     // ---- BAM header, in BGZF blocks of its own
     std::vector<uint8_t> head;
     head.insert(head.end(), {'B', 'A', 'M', 1});
@@ -269,20 +280,29 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
             if (!bgzf_block(head.data() + off, std::min(kBlockIn, head.size() - off), &df, &file)) { *err = "deflate failed"; return false; }
     }
     const uint64_t header_end = file.size();
+    stamp("header compressed");
 
     // ---- records: contiguous slices compressed independently (sortmardup/main.cpp:371-421)
     const size_t n = recs.size();
     // device compressor: the writer threads only gather records into pinned memory, a few of them saturate it
     const int T = device >= 0 ? std::max(1, std::min(threads, 8)) : std::max(1, threads);
-    const size_t n_slices = n ? std::min<size_t>((size_t)T * 4, (n + 4095) / 4096) : 0;
+    const size_t n_slices = n ? std::min<size_t>((size_t)T * (device >= 0 ? 16 : 4), (n + 4095) / 4096) : 0;
     std::vector<Slice> slices(n_slices);
     std::vector<size_t> lo(n_slices + 1, 0);
     for (size_t s = 0; s <= n_slices; ++s) lo[s] = n_slices ? n * s / n_slices : 0;
-    // the file is written while the slices are still being compressed: the calling thread writes slice s as soon as it
-    // is done (and drops its bytes), the pool compresses ahead
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) { *err = "cannot open " + path; return false; }
-    bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+    // the file is written while the slices are still being compressed: as soon as slice s is done its place in the file
+    // is known, and one of a few writer threads puts it there (pwrite) and drops its bytes; the pool compresses ahead
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { *err = "cannot open " + path; return false; }
+    auto put_at = [fd](const uint8_t* p, size_t len, uint64_t at) -> bool {
+        while (len) {
+            const ssize_t w = pwrite(fd, p, len, (off_t)at);
+            if (w <= 0) { if (w < 0 && errno == EINTR) continue; return false; }
+            p += w; len -= (size_t)w; at += (uint64_t)w;
+        }
+        return true;
+    };
+    std::atomic<bool> write_ok{put_at(file.data(), file.size(), 0)};
     std::vector<uint64_t> base(n_slices + 1, header_end);
     std::string dev_err_copy;
     {
@@ -300,6 +320,7 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
                 if (device >= 0) {
                     dv.reset(new DeviceSlice);
                     dev_ok = dv->create(device, (uint64_t)kDeviceBatchBlocks * kBlockIn, kDeviceBatchBlocks);
+                    stamp("a writer's batches are ready");
                 } else {
                     df.reset(new Deflater(level));
                 }
@@ -316,20 +337,45 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
                     cv.notify_all();
                 }
             });
+        std::vector<std::thread> writers;
+        std::vector<size_t> wq;                 // slices whose place is known, not yet written
+        size_t wq_next = 0; bool wq_closed = false;
+        std::mutex wmu; std::condition_variable wcv;
+        for (int t = 0; t < 4; ++t)
+            writers.emplace_back([&]() {
+                for (;;) {
+                    size_t s;
+                    {
+                        std::unique_lock<std::mutex> lk(wmu);
+                        wcv.wait(lk, [&] { return wq_next < wq.size() || wq_closed; });
+                        if (wq_next >= wq.size()) return;
+                        s = wq[wq_next++];
+                    }
+                    if (slices[s].ok && !put_at(slices[s].bytes.data(), slices[s].bytes.size(), base[s])) write_ok = false;
+                    std::vector<uint8_t>().swap(slices[s].bytes);
+                }
+            });
         for (size_t s = 0; s < n_slices; ++s) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[s] != 0; }); }
             base[s + 1] = base[s] + slices[s].bytes.size();
-            if (ok && slices[s].ok) ok = fwrite(slices[s].bytes.data(), 1, slices[s].bytes.size(), f) == slices[s].bytes.size();
-            std::vector<uint8_t>().swap(slices[s].bytes);
+            if (s == 0) stamp("first slice compressed");
+            { std::lock_guard<std::mutex> g(wmu); wq.push_back(s); }
+            wcv.notify_one();
         }
+        { std::lock_guard<std::mutex> g(wmu); wq_closed = true; }
+        wcv.notify_all();
+        stamp("last slice compressed");
         for (auto& th : pool) th.join();
+        stamp("compressors released");
+        for (auto& th : writers) th.join();
+        stamp("file written");
         dev_err_copy = dev_err;
     }
     for (size_t s = 0; s < n_slices; ++s)
-        if (!slices[s].ok) { fclose(f); *err = device >= 0 ? "device compressor: " + dev_err_copy : std::string("deflate failed"); return false; }
+        if (!slices[s].ok) { close(fd); *err = device >= 0 ? "device compressor: " + dev_err_copy : std::string("deflate failed"); return false; }
     static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    ok = ok && fwrite(eof_block, 1, 28, f) == 28;
-    ok = (fclose(f) == 0) && ok;
+    bool ok = write_ok.load() && put_at(eof_block, 28, base[n_slices]);
+    ok = (close(fd) == 0) && ok;
     if (!ok) { *err = "short write to " + path; return false; }
 
     // ---- BAI (merge of the per-slice offsets, the job of the reference's merge_index)
@@ -378,9 +424,10 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
         for (uint64_t v : ri.linear) put<uint64_t>(bai, v);
     }
     put<uint64_t>(bai, n_no_coor);
+    stamp("index built");
 
     // ---- the index file
-    f = fopen((path + ".bai").c_str(), "wb");
+    FILE* f = fopen((path + ".bai").c_str(), "wb");
     if (!f) { *err = "cannot open " + path + ".bai"; return false; }
     ok = fwrite(bai.data(), 1, bai.size(), f) == bai.size();
     ok = (fclose(f) == 0) && ok;

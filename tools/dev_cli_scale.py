@@ -28,6 +28,7 @@ def run(extra, tag):
     rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6          # largest child so far, GB
     print(f"--- {tag}: wall {wall:.2f} s = {n / wall / 1e6:.2f} Mrecords/s end to end, peak RSS {rss:.2f} GB (text {size / 1e9:.2f} GB)")
     print(res.stdout.strip(), flush=True)
+    if res.stderr.strip(): print(res.stderr.strip()[-3000:], flush=True)
     h = hashlib.md5()
     with open(bam, "rb") as f:
         for blk in iter(lambda: f.read(1 << 24), b""):
@@ -35,9 +36,11 @@ def run(extra, tag):
     return h.hexdigest(), os.path.getsize(bam)
 
 
-a = run([], "default slices (32 MB)")
-b = run(["-s", str(8 << 20)], "8 MB slices")
+a = run([], "default (8 MB slices, BGZF on the device)")
+b = run(["-s", str(32 << 20)], "32 MB slices")
 print("BAM size", a[1], "identical output for both slice sizes:", a == b)
+z = run(["-z", "zlib"], "-z zlib (level 6 on the writer threads)")
+print("BAM size with zlib", z[1], "device / zlib = %.3f" % (a[1] / z[1]))
 if len(sys.argv) > 4:
     # the same tool fed through stdin by the generator (no text file at all): argv[4] records
     n2 = int(sys.argv[4])
