@@ -315,10 +315,19 @@ int main(int argc, char** argv) {
 
     // ---- mark + compress + write
     std::vector<bamout::RecordRef> out(n);
-    for (size_t q = 0; q < n; ++q) {
-        const uint32_t arrival = order[q];
-        const Kept& k = by_arrival[arrival];
-        out[q] = bamout::RecordRef{k.blob, k.len, k.tid, k.beg, k.end, dup[arrival] != 0, k.mapped};
+    {
+        // a gather with random reads from by_arrival: spread over the threads
+        std::vector<std::thread> gang;
+        const size_t T = (size_t)std::max(1, std::min(threads, 16));
+        for (size_t t = 0; t < T; ++t)
+            gang.emplace_back([&, t]() {
+                for (size_t q = n * t / T, e = n * (t + 1) / T; q < e; ++q) {
+                    const uint32_t arrival = order[q];
+                    const Kept& k = by_arrival[arrival];
+                    out[q] = bamout::RecordRef{k.blob, k.len, k.tid, k.beg, k.end, dup[arrival] != 0, k.mapped};
+                }
+            });
+        for (auto& th : gang) th.join();
     }
     std::string err;
     if (!bamout::write_bam(out_path, hdr, out, threads, level, device_deflate ? device : -1, &err)) { fprintf(stderr, "write: %s\n", err.c_str()); return 1; }

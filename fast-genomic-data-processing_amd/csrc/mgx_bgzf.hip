@@ -50,6 +50,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+constexpr u32 kWin = 960;                       // positions per match window: 15 wavefronts extend matches, the 16th feeds them
 constexpr int kNT = 1024;                      // threads per workgroup = positions per match window (16 wavefronts: one block per CU, LDS-bound)
 constexpr int kHashBits = 12;
 constexpr u32 kMaxIn = MGX_BGZF_MAX_BLOCK_IN;
@@ -58,14 +59,15 @@ constexpr u32 kSlotSkew = 2;                   // a block starts at slot + 2: it
 constexpr u32 kPad = 320;                      // zero bytes after the input in LDS (match extension reads ahead)
 constexpr u32 kCrcPoly = 0xEDB88320u;
 constexpr int kNumLL = 286, kNumD = 30, kNumCL = 19;
-constexpr u32 kScratchPerWg = 65536u + 64u;     // u32 per workgroup: decided matches, then packed tokens, by position
+constexpr int kAhead = 4;                      // windows whose tokens are fetched ahead of their use (one memory round trip per 16)
+constexpr u32 kScratchPerWg = 65536u + kAhead * 1024u;     // u32 per workgroup: decided matches, then packed tokens, by position
 
 enum { V_OVER = 0, V_NUSED, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
 
 struct __attribute__((aligned(16))) Lds {
     u32 buf[(0x10000 + 512) / 4];              // the block's bytes (at the source's alignment), later the output words
     u32 head[1 << kHashBits];                  // hash -> last position + 1
-    u32 crc_tab[256];
+    u32 crc_tab[4][256];                       // slicing-by-4 tables
     u32 x2n[32];                               // x^(2^k) mod P
     u32 f_ll[288], f_d[32], f_cl[20];          // symbol counts
     u16 c_ll[288], c_d[32], c_cl[20];          // codes, bit-reversed for LSB-first output
@@ -76,7 +78,7 @@ struct __attribute__((aligned(16))) Lds {
     u8 depth[576];
     u32 bl_count[16], next_code[16];
     u32 wsum[kNT / 64];
-    u16 cand[2][kNT];                          // hash candidates (position + 1) of the current and the next window
+    u16 cand[2][kWin];                          // hash candidates (position + 1) of the current and the next window
     u32 cend[kNT];                             // parse: where chunk t's last token ends
     u64 mask[kNT];                             // parse: the positions of chunk t that start a token
     u32 fw[288];                               // huff_build's working copy of the counts
@@ -133,8 +135,14 @@ __device__ __forceinline__ void dist_code(u32 dist, u32* sym, u32* eb, u32* ev) 
     *ev = x & ((1u << *eb) - 1);
 }
 
+__device__ __forceinline__ u64 load64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ u32 match_len(const u8* a, const u8* b, u32 maxlen) {
     u32 len = 0;
+    while (len + 8 <= maxlen) {
+        const u64 x = load64(a + len) ^ load64(b + len);
+        if (x) return len + (u32)(__builtin_ctzll(x) >> 3);
+        len += 8;
+    }
     while (len + 4 <= maxlen) {
         const u32 x = load32(a + len) ^ load32(b + len);
         if (x) return len + (__builtin_ctz(x) >> 3);
@@ -144,12 +152,26 @@ __device__ __forceinline__ u32 match_len(const u8* a, const u8* b, u32 maxlen) {
     return len;
 }
 
+// Wavefront-wide inclusive scans on the DPP network (row shifts, then the row broadcasts of gfx9): six VALU operations,
+// no trip through the LDS crossbar as __shfl_up takes.  Lane 63 ends up with the reduction over the wavefront.
+template <typename Op>
+__device__ __forceinline__ u32 wave_scan_inclusive(u32 v, Op op) {
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));     // row_shr:1
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));     // row_shr:2
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));     // row_shr:4
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));     // row_shr:8
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1 and 3
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+struct OpAdd { __device__ __forceinline__ u32 operator()(u32 a, u32 b) const { return a + b; } };
+struct OpXor { __device__ __forceinline__ u32 operator()(u32 a, u32 b) const { return a ^ b; } };
+__device__ __forceinline__ u32 wave_last(u32 v) { return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+
 // Workgroup-wide exclusive prefix sum (wave shuffles, then the wave totals through LDS).  *total = sum of all values.
 __device__ __forceinline__ u32 block_scan(Lds& L, u32 v, u32* total) {
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    u32 inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const u32 o = __shfl_up(inc, off, 64); if (lane >= (u32)off) inc += o; }
+    const u32 inc = wave_scan_inclusive(v, OpAdd());
     __syncthreads();                                   // earlier readers of L.wsum are done
     if (lane == 63) L.wsum[wave] = inc;
     __syncthreads();
@@ -279,10 +301,15 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
     const u32 tid = threadIdx.x;
     u32* const mat = a.scratch + (size_t)blockIdx.x * kScratchPerWg;
 
-    for (u32 i = tid; i < 256; i += kNT) {
-        u32 c = i;
+    if (tid < 256) {
+        u32 c = tid;
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
-        L.crc_tab[i] = c;
+        L.crc_tab[0][tid] = c;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        u32 c = L.crc_tab[0][tid];
+        for (int k = 1; k < 4; ++k) { c = (c >> 8) ^ L.crc_tab[0][c & 0xffu]; L.crc_tab[k][tid] = c; }
     }
     if (tid == 0) {
         u32 p = 0x40000000u;                   // x^1
@@ -327,24 +354,29 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         // ---- 1. match search.  Wavefront 0 walks the hash table for the NEXT window, 64 positions per step: the LDS
         //         executes a wavefront's instructions in order, so a step's lookups see every earlier step's entries and
         //         none of its own -- candidates are blind to the last < 64 bytes only, and the outcome is deterministic.
+        const u32 plane = tid - kWin;                    // the producer's lane (wavefront 15)
         auto produce = [&](u32 base, u16* cb) {
 #pragma unroll
-            for (int k = 0; k < kNT / 64; ++k) {
-                const u32 p = base + (u32)k * 64u + tid;
+            for (int k = 0; k < (int)kWin / 64; ++k) {
+                const u32 p = base + (u32)k * 64u + plane;
                 u32 c = 0;
                 if (p + 4 <= n) {
                     const u32 h = (load32(in + p) * 2654435761u) >> (32 - kHashBits);
                     c = L.head[h];
                     atomicMax(&L.head[h], p + 1);
                 }
-                cb[k * 64 + (int)tid] = (u16)c;
+                cb[k * 64 + (int)plane] = (u16)c;
             }
         };
         __syncthreads();
-        if (tid < 64) produce(0, L.cand[0]);
+        if (tid >= kWin) produce(0, L.cand[0]);
         __syncthreads();
-        for (u32 w = 0, base = 0; base < n; ++w, base += kNT) {
-            if (tid < 64 && base + kNT < n) produce(base + kNT, L.cand[(w + 1) & 1]);
+        for (u32 w = 0, base = 0; base < n; ++w, base += kWin) {
+            if (tid >= kWin) {                              // the last wavefront only looks candidates up, one window ahead
+                if (base + kWin < n) produce(base + kWin, L.cand[(w + 1) & 1]);
+                __syncthreads();
+                continue;
+            }
             const u32 p = base + tid;
             u32 len = 0, dist = 0;
             if (p < n) {
@@ -373,7 +405,7 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             }
             // one-step lazy evaluation: a longer match starting at the next byte (the neighbouring lane's) wins; the decision
             // is a function of the position alone, whatever the parse does around it
-            const u32 len_next = __shfl_down(len, 1, 64);
+            const u32 len_next = (u32)__builtin_amdgcn_update_dpp(0, (int)len, 0x130, 0xf, 0xf, false);      // wave_shl:1: lane i reads lane i + 1
             if (a.lazy && (tid & 63u) != 63u && len_next > len) len = 0;
             mat[p] = len ? (len << 16 | dist) : 0u;
             __syncthreads();
@@ -386,19 +418,21 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         //         walk is repeated until no chunk's start moves (two or three rounds on BAM bytes, at most one per chunk).
         const u32 lo = tid * 64u;
         const u32 cl = lo < n ? min(64u, n - lo) : 0u;
-        u32 m[64];
+        u32 m2[32];                                        // the chunk's 64 token lengths (0 = literal), two per register
         {
             const uint4* v = reinterpret_cast<const uint4*>(mat + lo);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const uint4 x = v[q];
-                m[4 * q] = x.x >> 16; m[4 * q + 1] = x.y >> 16; m[4 * q + 2] = x.z >> 16; m[4 * q + 3] = x.w >> 16;
+                m2[2 * q] = (x.x >> 16) | (x.y & 0xffff0000u);
+                m2[2 * q + 1] = (x.z >> 16) | (x.w & 0xffff0000u);
             }
         }
+#define MGX_LEN_AT(i) (((i) & 1) ? m2[(i) >> 1] >> 16 : m2[(i) >> 1] & 0xffffu)
         auto walk = [&](u32 start) -> u32 {                 // chunk-relative; returns where the last token ends (may pass 64)
             u32 next = start;
 #pragma unroll
-            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) next += m[i] ? m[i] : 1u;
+            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) { const u32 l = MGX_LEN_AT(i); next += l ? l : 1u; }
             return next;
         };
         u32 cur_start = lo;
@@ -418,19 +452,23 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             u64 mask = 0;
             u32 next = cur_start - lo;
 #pragma unroll
-            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) { mask |= 1ull << i; next += m[i] ? m[i] : 1u; }
+            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) { mask |= 1ull << i; const u32 l = MGX_LEN_AT(i); next += l ? l : 1u; }
             L.mask[tid] = mask;
         }
+#undef MGX_LEN_AT
         // ---- 5. CRC-32 of the chunk, shifted to the end of the block
         {
             u32 c = tid == 0 ? 0xFFFFFFFFu : 0u;
-            for (u32 p = lo; p < lo + cl; ++p) c = L.crc_tab[(c ^ in[p]) & 0xffu] ^ (c >> 8);
+            u32 p = lo;
+            for (; p + 4 <= lo + cl; p += 4) {
+                const u32 x = c ^ load32(in + p);
+                c = L.crc_tab[3][x & 0xffu] ^ L.crc_tab[2][(x >> 8) & 0xffu] ^ L.crc_tab[1][(x >> 16) & 0xffu] ^ L.crc_tab[0][x >> 24];
+            }
+            for (; p < lo + cl; ++p) c = L.crc_tab[0][(c ^ in[p]) & 0xffu] ^ (c >> 8);
             u32 e = 8u * (n - (lo + cl)), xp = 0x80000000u;
             if (lo >= n) e = 0;
             for (int k = 0; e; ++k, e >>= 1) if (e & 1u) xp = multmodp(L.x2n[k], xp);
-            u32 part = multmodp(xp, c);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) part ^= __shfl_xor(part, off, 64);
+            const u32 part = wave_last(wave_scan_inclusive(multmodp(xp, c), OpXor()));
             if ((tid & 63u) == 0) L.wsum[tid >> 6] = part;
         }
         if (tid == 0) L.f_ll[256] = 1;             // end of block
@@ -441,26 +479,32 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             L.vars[V_CRC] = c ^ 0xFFFFFFFFu;
         }
         lap(2);
-        // ---- tokens, position-parallel: the position's token in packed form, and the symbol counts
-        for (u32 base = 0; base < n; base += kNT) {
-            const u32 p = base + tid;
-            u32 tok = kTokNone;
-            if (p < n && ((L.mask[p >> 6] >> (p & 63u)) & 1ull)) {
-                const u32 mm = mat[p];
-                const u32 len = mm >> 16;
-                if (len) {
-                    u32 ls, leb, lev, ds, deb, dev;
-                    length_code(len, &ls, &leb, &lev);
-                    dist_code(mm & 0xffffu, &ds, &deb, &dev);
-                    atomicAdd(&L.f_ll[ls], 1u);
-                    atomicAdd(&L.f_d[ds], 1u);
-                    tok = ls | lev << 9 | ds << 14 | dev << 19;
-                } else {
-                    tok = in[p];
-                    atomicAdd(&L.f_ll[tok], 1u);
+        // ---- tokens, position-parallel: the token starting at a position (or none) in packed form, and the symbol counts
+        const u32 n_win = (n + kNT - 1) / kNT;
+        for (u32 w0 = 0; w0 < n_win; w0 += kAhead) {
+            u32 mm[kAhead];
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) mm[j] = mat[(w0 + j) * kNT + tid];          // (in bounds: the array has 64 + kAhead windows)
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                const u32 p = (w0 + j) * kNT + tid;
+                u32 t = kTokNone;
+                if (p < n && ((L.mask[p >> 6] >> (p & 63u)) & 1ull)) {
+                    const u32 len = mm[j] >> 16;
+                    if (len) {
+                        u32 ls, leb, lev, ds, deb, dev;
+                        length_code(len, &ls, &leb, &lev);
+                        dist_code(mm[j] & 0xffffu, &ds, &deb, &dev);
+                        atomicAdd(&L.f_ll[ls], 1u);
+                        atomicAdd(&L.f_d[ds], 1u);
+                        t = ls | lev << 9 | ds << 14 | dev << 19;
+                    } else {
+                        t = in[p];
+                        atomicAdd(&L.f_ll[t], 1u);
+                    }
                 }
+                if (w0 + j < n_win) mat[p] = t;
             }
-            mat[p] = tok;
         }
         __syncthreads();
         lap(3);
@@ -544,29 +588,51 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             for (u32 w = tid; w < nw; w += kNT) L.buf[w] = 0;
             __syncthreads();
             for (u32 w = tid; w < ((hdr_bits + 31) >> 5); w += kNT) atomicOr(&L.buf[w], L.hdr[w]);
-            u32 carry = hdr_bits;
-            u32 nxt = mat[tid];
-            for (u32 base = 0; base < n; base += kNT) {
-                const u32 tok = nxt;
-                if (base + kNT < n) nxt = mat[base + kNT + tid];
-                const u32 nb = token_bits(L, tok);
-                u32 window_bits;
-                const u32 off = block_scan(L, nb, &window_bits);
-                if (nb) {
-                    BitSink s;
-                    s.start(L.buf, carry + off);
-                    const u32 ls = tok & 0x1FFu;
-                    s.put(L.c_ll[ls], L.l_ll[ls]);
-                    if (ls > 256) {
-                        const u32 ds = (tok >> 14) & 31u, leb = length_extra_bits(ls), deb = dist_extra_bits(ds);
-                        if (leb) s.put((tok >> 9) & 31u, leb);
-                        s.put(L.c_d[ds], L.l_d[ds]);
-                        if (deb) s.put(tok >> 19, deb);
-                    }
-                    s.finish();
+            // bit offset of every (window, wavefront) group of 64 positions: their totals, scanned in position order
+            const u32 lane = tid & 63u, wave = tid >> 6;
+            L.cend[tid] = 0;
+            __syncthreads();
+            for (u32 w0 = 0; w0 < n_win; w0 += kAhead) {
+                u32 t4[kAhead];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) t4[j] = mat[(w0 + j) * kNT + tid];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    const u32 v = wave_last(wave_scan_inclusive(w0 + j < n_win ? token_bits(L, t4[j]) : 0u, OpAdd()));
+                    if (lane == 0 && w0 + j < n_win) L.cend[(w0 + j) * (kNT / 64) + wave] = v;
                 }
-                carry += window_bits;
             }
+            __syncthreads();
+            u32 all_bits;
+            const u32 group_off = block_scan(L, L.cend[tid], &all_bits);
+            __syncthreads();
+            L.cend[tid] = hdr_bits + group_off;
+            __syncthreads();
+            for (u32 w0 = 0; w0 < n_win; w0 += kAhead) {
+                u32 t4[kAhead];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) t4[j] = mat[(w0 + j) * kNT + tid];
+#pragma unroll
+                for (int j = 0; j < kAhead; ++j) {
+                    const u32 t = t4[j];
+                    const u32 nb = w0 + j < n_win ? token_bits(L, t) : 0u;
+                    const u32 inc = wave_scan_inclusive(nb, OpAdd());
+                    if (nb) {
+                        BitSink s;
+                        s.start(L.buf, L.cend[(w0 + j) * (kNT / 64) + wave] + inc - nb);
+                        const u32 ls = t & 0x1FFu;
+                        s.put(L.c_ll[ls], L.l_ll[ls]);
+                        if (ls > 256) {
+                            const u32 ds = (t >> 14) & 31u, leb = length_extra_bits(ls), deb = dist_extra_bits(ds);
+                            if (leb) s.put((t >> 9) & 31u, leb);
+                            s.put(L.c_d[ds], L.l_d[ds]);
+                            if (deb) s.put(t >> 19, deb);
+                        }
+                        s.finish();
+                    }
+                }
+            }
+            const u32 carry = hdr_bits + all_bits;
             if (tid == 0) { BitSink s; s.start(L.buf, carry); s.put(L.c_ll[256], L.l_ll[256]); s.finish(); }
             __syncthreads();
             u32* payw = reinterpret_cast<u32*>(pay);
@@ -685,8 +751,8 @@ int mgx_bgzf_create(int device, unsigned flags, mgx_bgzf_t** out) {
     HIP_TRY(hipMalloc((void**)&c->d_n_stored, sizeof(u32)));
     HIP_TRY(hipMemset(c->d_n_stored, 0, sizeof(u32)));
     if (const char* e = getenv("MGX_BGZF_PROF")) if (atoi(e)) {
-        HIP_TRY(hipMalloc((void**)&c->d_prof, 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->d_prof, 0, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&c->d_prof, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)k_bgzf_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
     *out = c.release();
@@ -700,10 +766,11 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
     (void)hipFree(c->d_scratch);
     (void)hipFree(c->d_n_stored);
     if (c->d_prof) {
-        unsigned long long p[8];
-        if (hipMemcpy(p, c->d_prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess && c->n_blocks)
+        unsigned long long p[16];
+        if (hipMemcpy(p, c->d_prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess && c->n_blocks) {
             fprintf(stderr, "mgx_bgzf cycles per block: load %llu, match %llu, parse+crc %llu, tokens %llu, huffman %llu, header %llu, emit %llu\n", p[0] / c->n_blocks,
                     p[1] / c->n_blocks, p[2] / c->n_blocks, p[3] / c->n_blocks, p[4] / c->n_blocks, p[5] / c->n_blocks, p[6] / c->n_blocks);
+        }
         (void)hipFree(c->d_prof);
     }
     delete c;
