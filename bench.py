@@ -246,6 +246,76 @@ def smithwaterman_leg(pkg, synth, args, rank, local_rank):
     return out
 
 
+def bgzf_leg(pkg, synth, args, rank, local_rank):
+    """Row F3, output end (widening): BGZF compression of a coordinate-sorted BAM record stream on the device, the job of
+    htslib's bgzf_compress / zlib in the reference's writer threads.  Rank 0 only.  Input batches resident in pinned host
+    memory; `value` is kernel-only (blocks resident in HBM), the pinned-to-pinned rate is reported beside it."""
+    if rank != 0:
+        return None
+    import zlib
+    B, per = 0xff00, 2048
+    n_batches = max(3, (args.bgzf_mb << 20) // (per * B))
+    comp = pkg.BgzfCompressor(local_rank)
+    src = synth.gen_bam_record_bytes(3 * per * B, 0x5EED0030)
+    batches = [pkg.BgzfBatch(comp, per * B, per) for _ in range(3)]
+    for k, b in enumerate(batches):
+        b.input[:] = src[k * per * B:(k + 1) * per * B]
+        b.offsets[:] = np.arange(per + 1, dtype=np.uint64) * B
+    for b in batches:
+        b.submit(per)
+    first = [b.wait() for b in batches]
+    ok = all(zlib.crc32(b"".join(zlib.decompress(bytes(o[int(oo[i]) + 18:int(oo[i + 1]) - 8]), -15) for i in range(0, per, 97))) ==
+             zlib.crc32(b"".join(bytes(src[(k * per + i) * B:(k * per + i + 1) * B]) for i in range(0, per, 97)))
+             for k, (o, oo) in enumerate(first))
+    out_bytes = sum(int(oo[-1]) for _, oo in first)
+    ks = []
+    t0 = time.perf_counter()
+    for i in range(n_batches):
+        b = batches[i % 3]
+        if i >= 3:
+            lib_wait(comp, b); ks.append(comp.stats()["ms_kernels"])
+        b.submit(per)
+    for i in range(n_batches, n_batches + 3):
+        lib_wait(comp, batches[i % 3]); ks.append(comp.stats()["ms_kernels"])
+    dt = time.perf_counter() - t0
+    st = comp.stats()
+    kernel_ms = float(np.median(ks))
+    ratio = out_bytes / (3 * per * B)
+    alg = per * B * (1 + ratio)                       # read the input once, write the compressed blocks once
+    out = {"metric": "BGZF compression GB/s of BAM bytes (LZ77 + dynamic Huffman + CRC-32 per 65280-byte block, on the device)",
+           "value": per * B / kernel_ms / 1e6, "unit": "GB/s", "dtype": "u8",
+           "config": {"workload": "coordinate-sorted BAM records of BASELINE.json configs[3] (150-base reads, qualities U[2,41]), blocks of 65280 bytes",
+                      "blocks_per_batch": per, "batches": n_batches, "bytes": n_batches * per * B},
+           "compressed_over_input": ratio, "pinned_to_pinned_GBps": n_batches * per * B / dt / 1e9, "blocks_stored": int(st["n_stored"]),
+           "inflates_to_input": bool(ok),
+           "roofline": {"bound": "hbm", "limiter": "lds-latency", "achieved": alg / kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_bgzf_deflate", "kernel_ms": kernel_ms,
+                        "kernel_ms_source": "HIP events around the deflate + offsets + pack kernels of a batch, median over the batches",
+                        "alg_bytes_per_launch": alg,
+                        "note": "entropy coding: serial dependences inside a block (hash chains, Huffman construction, bit offsets) run in "
+                                "LDS, one 64 KB block per workgroup; the HBM roof is not what binds it"}}
+    if not args.no_cpu_baseline:
+        sample = bytes(src[:256 * B])
+        t0 = time.perf_counter()
+        z = sum(len(zlib.compress(sample[i:i + B], 6)) for i in range(0, len(sample), B))
+        dtz = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": len(sample) / dtz / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
+                               "sample": f"the first 256 blocks through zlib level 6 (what bgzf_compress calls, bgzf.c:610) on one core, {dtz:.2f} s",
+                               "compressed_over_input": z / len(sample)}
+    for b in batches:
+        b.close()
+    comp.close()
+    return out
+
+
+def lib_wait(comp, b):
+    """mgx_bgzf_batch_wait without copying the result out of the pinned buffer"""
+    import ctypes
+    o, oo = ctypes.c_void_p(), ctypes.c_void_p()
+    if comp.lib.mgx_bgzf_batch_wait(comp.h, b.b, ctypes.byref(o), ctypes.byref(oo)):
+        raise RuntimeError(comp.lib.mgx_last_error().decode())
+
+
 def timed_resident(eng, batch, steps, warmup, barrier):
     """W untimed + K timed runs of a resident batch, bracketed by barrier + synchronize.  HIP events are
     recorded on the kernel's own stream around every launch of every run; batch.stats() after the
@@ -372,6 +442,7 @@ def main():
                     help="records of the sortmardup leg (BASELINE.json configs[3]; ONE data set, sharded over the ranks); 0 disables it")
     ap.add_argument("--sort-steps", type=int, default=5)
     ap.add_argument("--sw-pairs", type=int, default=20000, help="Smith-Waterman pairs (row F4 leg; 0 skips it)")
+    ap.add_argument("--bgzf-mb", type=int, default=1024, help="MB of BAM bytes through the device BGZF compressor (row F3 leg; 0 skips it)")
     ap.add_argument("--queue-lanes", type=int, default=0, help="host lanes of the work queue (default: min(8, cores / ranks))")
     ap.add_argument("--no-ragged", action="store_true", help="skip sub-run 2b (ragged lengths)")
     ap.add_argument("--no-regions", action="store_true", help="skip the row-F1 leg (1000 regions of 40 x 25)")
@@ -510,6 +581,7 @@ def main():
     if args.sort_records > 0:
         sort_line = sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend)
     sw_line = smithwaterman_leg(pkg, synth, args, rank, local_rank) if args.sw_pairs > 0 else None
+    bgzf_line = bgzf_leg(pkg, synth, args, rank, local_rank) if args.bgzf_mb > 0 else None
     mixed_line = mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_over_ranks) if args.mixed else None
     if rank == 0:
         if not args.no_regions:
@@ -520,6 +592,8 @@ def main():
             line["sortmardup"] = sort_line
         if sw_line is not None:
             line["smithwaterman"] = sw_line
+        if bgzf_line is not None:
+            line["bgzf"] = bgzf_line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

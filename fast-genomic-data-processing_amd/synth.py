@@ -524,3 +524,45 @@ def gen_sw_pairs(n_pairs, seed, ref_range=(40, 400), alt_range=(20, 250), strate
     strat = np.array(strategies, dtype=np.uint8)[rng.integers(0, len(strategies), n_pairs)]
     return dict(ref_off=ref_off, ref=np.concatenate(refs) if refs else np.zeros(0, np.uint8), alt_off=alt_off,
                 alt=np.concatenate(alts) if alts else np.zeros(0, np.uint8), strategy=strat)
+
+
+def gen_bam_record_bytes(n_bytes, seed, read_len=150, qual_bins=None):
+    """A coordinate-sorted BAM record stream as the writer sees it (block_size + fixed fields + read name + CIGAR +
+    4-bit bases + qualities + tags), the input of the BGZF compressor: names `SYN:1:FC:1:<tile>:<x>:<y>`, 150-base
+    reads, random bases, qualities U[2,41] per base as in BASELINE.json configs[3] (or drawn from `qual_bins` in runs,
+    the binned qualities of newer instruments), the tags of an aligner.  Vectorised; returns a uint8 array."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    name_len = 28                                         # "SYN:1:FC:1:tttt:xxxxx:yyyyy\0"
+    aux = b"NMC\x01MDZ150\0RGZgroup1\0ASC\x96XSC\x00"
+    rec_len = 32 + name_len + 4 + (read_len + 1) // 2 + read_len + len(aux)
+    n = n_bytes // (rec_len + 4) + 1
+    a = np.zeros((n, rec_len + 4), dtype=np.uint8)
+
+    def put(col, values, dtype):
+        v = np.ascontiguousarray(values.astype(dtype)).view(np.uint8).reshape(n, -1)
+        a[:, col:col + v.shape[1]] = v
+    pos = np.cumsum(rng.randint(0, 6, n)).astype(np.int64) + 10000
+    put(0, np.full(n, rec_len), "<i4")
+    put(4, np.zeros(n), "<i4"); put(8, pos, "<i4")
+    a[:, 12] = name_len; a[:, 13] = rng.randint(0, 61, n)
+    put(14, 4681 + (pos >> 14), "<u2"); put(16, np.ones(n), "<u2")
+    put(18, rng.choice(np.array([99, 147, 83, 163, 1123, 1171]), n), "<u2"); put(20, np.full(n, read_len), "<i4")
+    put(24, np.zeros(n), "<i4"); put(28, pos + rng.randint(-400, 400, n), "<i4"); put(32, rng.randint(-600, 600, n), "<i4")
+    digits = lambda x, w: ((x[:, None] // 10 ** np.arange(w - 1, -1, -1)[None, :]) % 10 + 48).astype(np.uint8)  # noqa: E731
+    a[:, 36:47] = np.frombuffer(b"SYN:1:FC:1:", dtype=np.uint8)
+    a[:, 47:51] = digits(rng.randint(1101, 2679, n), 4); a[:, 51] = 58
+    a[:, 52:57] = digits(rng.randint(1000, 32000, n), 5); a[:, 57] = 58
+    a[:, 58:63] = digits(rng.randint(1000, 99000, n), 5); a[:, 63] = 0
+    c = 36 + name_len
+    put(c, np.full(n, read_len << 4), "<u4"); c += 4
+    nb = (read_len + 1) // 2
+    b = 1 << rng.randint(0, 4, (n, 2 * nb)).astype(np.uint8)
+    a[:, c:c + nb] = (b[:, 0::2] << 4) | b[:, 1::2]; c += nb
+    if qual_bins is None:
+        a[:, c:c + read_len] = rng.randint(2, 42, (n, read_len))
+    else:
+        picks = rng.choice(np.asarray(qual_bins, dtype=np.uint8), (n, read_len // 3 + 1))
+        a[:, c:c + read_len] = np.repeat(picks, 3, axis=1)[:, :read_len]
+    c += read_len
+    a[:, c:c + len(aux)] = np.frombuffer(aux, dtype=np.uint8)
+    return a.reshape(-1)[:n_bytes].copy()
