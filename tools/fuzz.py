@@ -1,5 +1,5 @@
-"""Randomised soak: loops over seeded random inputs for the three paths and compares the device with the
-oracles (bit-exact for sort/dedup and Smith-Waterman, 1e-5 for PairHMM).  usage: fuzz.py [seconds] [seed0]"""
+"""Randomised soak: loops over seeded random inputs for the paths and compares the device with the oracles
+(bit-exact for sort/dedup and Smith-Waterman, 1e-5 for PairHMM, zlib's inflate for the BGZF blocks).  usage: fuzz.py [seconds] [seed0]"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,11 +13,14 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ph, sd, sw = pkg.PairHMMEngine(0), pkg.SortDedupEngine(0), pkg.SmithWatermanEngine(0)
 oph, osd, osw = PairHMMOracle(_ensure_oracle()), SortDedupOracle(), SmithWatermanOracle()
 rng = np.random.default_rng(seed0)
-t0 = time.time(); it = 0; fails = 0; counts = {"sort": 0, "pairhmm": 0, "regions": 0, "sw": 0, "shards": 0, "queue": 0}
+t0 = time.time(); it = 0; fails = 0; counts = {"sort": 0, "pairhmm": 0, "regions": 0, "sw": 0, "shards": 0, "queue": 0, "bgzf": 0}
+import zlib
+bz = pkg.BgzfCompressor(0)
+bam_bytes = synth.gen_bam_record_bytes(6_000_000, 99, qual_bins=(2, 11, 25, 37))
 queue = pkg.PairHMMQueue(devices=(0, 0), lanes_per_device=2, depth=2, batch_pairs=700)
 while time.time() - t0 < budget:
     seed = int(rng.integers(1, 2**31 - 1)); it += 1
-    kind = it % 6
+    kind = it % 7
     try:
         if kind == 0:
             kw = dict(n_contigs=int(rng.integers(1, 6)), contig_len=int(rng.choice([5000, 60000, 400000, 3000000])),
@@ -78,6 +81,26 @@ while time.time() - t0 < budget:
             o2, d2 = sd.results()
             ok &= bool(np.array_equal(o2, wo) and np.array_equal(d2, wd))
             counts["shards"] += 1
+        elif kind == 6:
+            # BGZF: ragged pieces of mixed content; every block must inflate to its piece with the right CRC and size
+            nb = int(rng.integers(1, 300))
+            sizes = rng.integers(0, 65281, nb); sizes[rng.integers(0, nb, max(1, nb // 8))] = rng.integers(0, 40, max(1, nb // 8))
+            total = int(sizes.sum()); offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+            start = int(rng.integers(0, len(bam_bytes) - 1))
+            data = np.resize(np.roll(bam_bytes, -start), total).copy() if total else np.zeros(0, dtype=np.uint8)
+            for i in rng.integers(0, nb, nb // 6 + 1):      # some pieces of noise, of few symbols, of one byte value
+                a_, b_ = int(offs[i]), int(offs[i + 1]); mode = int(rng.integers(0, 3))
+                data[a_:b_] = rng.integers(0, 256 if mode == 0 else 4, b_ - a_, dtype=np.uint8) if mode < 2 else int(rng.integers(0, 256))
+            out, oo = bz.compress(data, offs)
+            raw, ob = data.tobytes(), bytes(out)
+            ok = len(oo) == nb + 1 and int(oo[-1]) == len(ob)
+            for i in range(nb):
+                blk = ob[int(oo[i]):int(oo[i + 1])]; want = raw[int(offs[i]):int(offs[i + 1])]
+                dz = zlib.decompressobj(-15)
+                ok &= blk[:4] == b"\x1f\x8b\x08\x04" and int.from_bytes(blk[16:18], "little") + 1 == len(blk)
+                ok &= dz.decompress(blk[18:-8]) + dz.flush() == want and dz.eof
+                ok &= int.from_bytes(blk[-8:-4], "little") == zlib.crc32(want) and int.from_bytes(blk[-4:], "little") == len(want)
+            counts["bgzf"] += 1
         elif kind == 5:
             # the host work queue: a stream cut into small batches over two lanes x two "devices" equals one call
             if it % 12 == 5:
