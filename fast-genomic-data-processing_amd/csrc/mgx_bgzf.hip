@@ -78,6 +78,7 @@ struct __attribute__((aligned(16))) Lds {
     u8 depth[576];
     u32 bl_count[16], next_code[16];
     u32 wsum[kNT / 64];
+    u64 smask[6];                              // header: which of the (up to 316) code lengths start a run
     u16 cand[2][kWin];                          // hash candidates (position + 1) of the current and the next window
     u32 cend[kNT];                             // parse: where chunk t's last token ends
     u64 mask[kNT];                             // parse: the positions of chunk t that start a token
@@ -186,8 +187,10 @@ __device__ __forceinline__ u32 block_scan(Lds& L, u32 v, u32* total) {
 // At least two symbols get a code (inflate accepts no incomplete literal/length or code-length code).
 // Parallel but for the merge itself: ranks by counting, leaf depths by walking up the parent links, code values by
 // counting the earlier symbols of the same length.
-__device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int limit, u8* len, u16* code) {
+__device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int limit, u8* len, u16* code, unsigned long long* prof = nullptr) {
     const int tid = (int)threadIdx.x;
+    long long tp = prof ? clock64() : 0;
+    auto lap = [&](int k) { if (prof && tid == 0) { const long long t = clock64(); atomicAdd(&prof[k], (unsigned long long)(t - tp)); tp = t; } };
     __syncthreads();
     if (tid < N) L.fw[tid] = freq_in[tid];            // the caller's counts stay as they are (they price the block)
     u32* const freq = L.fw;
@@ -198,6 +201,7 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
         if (used == 0) { freq[0] = 1; freq[1] = 1; }
         else if (used == 1) freq[freq[0] ? 1 : 0] = 1;
     }
+    lap(8);
     for (;;) {
         __syncthreads();
         if (tid < 16) L.bl_count[tid] = 0;
@@ -215,10 +219,12 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
             }
         }
         __syncthreads();
+        lap(9);
         const int n = (int)L.vars[V_NUSED];
         if (tid == 0) {
             // two-queue merge: leaves in weight order, internal nodes in creation order.  The heads of both queues are
-            // kept in registers and refilled with loads that do not depend on the step's result.
+            // kept in registers and refilled with loads that do not depend on the step's result.  (One lane, ~600 cycles
+            // per step with nothing else to issue on the SIMD; four heads per queue measured slower than two.)
             const u32 kInf = 0xFFFFFFFFu;
             int i = 0, j = 0;
             u32 la = L.wl[0], lb = n > 1 ? L.wl[1] : kInf, ia = kInf, ib = kInf;
@@ -240,6 +246,7 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
             }
         }
         __syncthreads();
+        lap(10);
         if (tid < n) {                               // depth of leaf tid: steps to the root (node 2n - 2)
             int d = 0;
             for (int id = tid; id != 2 * n - 2; id = L.parent[id]) ++d;
@@ -248,6 +255,7 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
             atomicAdd(&L.bl_count[d < 16 ? d : 15], 1u);
         }
         __syncthreads();
+        lap(11);
         if (!L.vars[V_OVER]) break;
         if (tid < N) { const u32 f = freq[tid]; if (f) freq[tid] = (f + 1) >> 1; }     // flatter, still >= 1
     }
@@ -269,6 +277,7 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
         code[tid] = (u16)c;
     }
     __syncthreads();
+    lap(12);
 }
 
 struct BitSink {          // LSB-first bit writer into 32-bit words shared with other writers (OR)
@@ -356,17 +365,23 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         //         none of its own -- candidates are blind to the last < 64 bytes only, and the outcome is deterministic.
         const u32 plane = tid - kWin;                    // the producer's lane (wavefront 15)
         auto produce = [&](u32 base, u16* cb) {
+            // three passes so that the LDS sees the 15 lookup / insert pairs back to back (its in-order execution is what
+            // orders them), instead of a wait for every lookup's result before the next pair is issued
+            constexpr int kSteps = (int)kWin / 64;
+            u32 h[kSteps], c[kSteps];
 #pragma unroll
-            for (int k = 0; k < (int)kWin / 64; ++k) {
+            for (int k = 0; k < kSteps; ++k) {
                 const u32 p = base + (u32)k * 64u + plane;
-                u32 c = 0;
-                if (p + 4 <= n) {
-                    const u32 h = (load32(in + p) * 2654435761u) >> (32 - kHashBits);
-                    c = L.head[h];
-                    atomicMax(&L.head[h], p + 1);
-                }
-                cb[k * 64 + (int)plane] = (u16)c;
+                h[k] = p + 4 <= n ? (load32(in + p) * 2654435761u) >> (32 - kHashBits) : 0xFFFFFFFFu;
             }
+#pragma unroll
+            for (int k = 0; k < kSteps; ++k) {
+                const u32 p = base + (u32)k * 64u + plane;
+                c[k] = 0;
+                if (h[k] != 0xFFFFFFFFu) { c[k] = L.head[h[k]]; atomicMax(&L.head[h[k]], p + 1); }
+            }
+#pragma unroll
+            for (int k = 0; k < kSteps; ++k) cb[k * 64 + (int)plane] = (u16)c[k];
         };
         __syncthreads();
         if (tid >= kWin) produce(0, L.cand[0]);
@@ -510,62 +525,89 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         lap(3);
 
         // ---- 3. codes
-        huff_build(L, L.f_ll, kNumLL, 15, L.l_ll, L.c_ll);
+        huff_build(L, L.f_ll, kNumLL, 15, L.l_ll, L.c_ll, a.prof);
         huff_build(L, L.f_d, kNumD, 15, L.l_d, L.c_d);
         lap(4);
-        if (tid == 0) {
-            int nlit = kNumLL, ndist = kNumD;
-            while (nlit > 257 && L.l_ll[nlit - 1] == 0) --nlit;
-            while (ndist > 1 && L.l_d[ndist - 1] == 0) --ndist;
-            L.vars[V_NLIT] = nlit; L.vars[V_NDIST] = ndist;
-            // run-length code of the nlit + ndist code lengths (symbols 16 / 17 / 18)
-            const int total = nlit + ndist;
-            auto length_at = [&](int i) -> u32 { return i < nlit ? L.l_ll[i] : L.l_d[i - nlit]; };
-            int ns = 0;
-            auto emit = [&](u32 sym, u32 extra) { L.clsym[ns++] = (u16)(sym | extra << 8); L.f_cl[sym] += 1; };
-            for (int i = 0; i < total;) {
-                const u32 v = length_at(i);
-                int r = 1;
-                while (i + r < total && length_at(i + r) == v) ++r;
-                i += r;
+        // the header (RFC 1951 3.2.7), in parallel: the nlit + ndist code lengths are cut into runs (ballots), every run
+        // knows how many code-length symbols it becomes (16: repeat 3-6, 17 / 18: zeros 3-10 / 11-138), a scan places them
+        if (tid == 0) { L.vars[V_NLIT] = 257; L.vars[V_NDIST] = 1; }
+        for (u32 i = tid; i < 192; i += kNT) L.hdr[i] = 0;
+        __syncthreads();
+        if (tid < (u32)kNumLL && L.l_ll[tid]) atomicMax(&L.vars[V_NLIT], tid + 1);
+        if (tid < (u32)kNumD && L.l_d[tid]) atomicMax(&L.vars[V_NDIST], tid + 1);
+        __syncthreads();
+        {
+            const u32 nlit = L.vars[V_NLIT], total = nlit + L.vars[V_NDIST];
+            auto length_at = [&](u32 i) -> u32 { return i < nlit ? L.l_ll[i] : L.l_d[i - nlit]; };
+            const u32 v = tid < total ? length_at(tid) : 0xFFu;
+            const bool start = tid < total && (tid == 0 || length_at(tid - 1) != v);
+            const u64 bal = __ballot(start);
+            if ((tid & 63u) == 0 && tid < 384) L.smask[tid >> 6] = bal;
+            __syncthreads();
+            u32 cnt = 0, run = 0;
+            if (start) {
+                u32 next = total;
+                const u32 wv = tid >> 6, ln = tid & 63u;
+                const u64 rest = ln == 63 ? 0ull : (L.smask[wv] >> (ln + 1));
+                if (rest) next = tid + 1 + (u32)__builtin_ctzll(rest);
+                else for (u32 w = wv + 1; w < 6; ++w) { const u64 mk = L.smask[w]; if (mk) { next = w * 64 + (u32)__builtin_ctzll(mk); break; } }
+                if (next > total) next = total;
+                run = next - tid;
+                if (v == 0) { const u32 rem = run % 138; cnt = run / 138 + (rem >= 3 ? 1u : rem); }
+                else { const u32 rem = (run - 1) % 6; cnt = 1 + (run - 1) / 6 + (rem >= 3 ? 1u : rem); }
+            }
+            u32 ns;
+            u32 at = block_scan(L, cnt, &ns);
+            if (start) {
+                auto emit = [&](u32 sym, u32 extra) { L.clsym[at++] = (u16)(sym | extra << 8); atomicAdd(&L.f_cl[sym], 1u); };
                 if (v == 0) {
-                    while (r > 0) {
-                        if (r >= 11) { const int t = r < 138 ? r : 138; emit(18, (u32)(t - 11)); r -= t; }
-                        else if (r >= 3) { emit(17, (u32)(r - 3)); r = 0; }
-                        else { emit(0, 0); --r; }
-                    }
+                    u32 r = run;
+                    for (; r >= 138; r -= 138) emit(18, 127);
+                    if (r >= 11) emit(18, r - 11); else if (r >= 3) emit(17, r - 3); else for (; r; --r) emit(0, 0);
                 } else {
-                    emit(v, 0); --r;
-                    while (r > 0) {
-                        if (r >= 3) { const int t = r < 6 ? r : 6; emit(16, (u32)(t - 3)); r -= t; }
-                        else { emit(v, 0); --r; }
-                    }
+                    emit(v, 0);
+                    u32 r = run - 1;
+                    for (; r >= 6; r -= 6) emit(16, 3);
+                    if (r >= 3) emit(16, r - 3); else for (; r; --r) emit(v, 0);
                 }
             }
-            L.vars[V_NCLSYM] = ns;
+            if (tid == 0) L.vars[V_NCLSYM] = ns;
         }
         huff_build(L, L.f_cl, kNumCL, 7, L.l_cl, L.c_cl);
         if (tid == 0) {
             const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-            for (int i = 0; i < 192; ++i) L.hdr[i] = 0;
             u32 word = 0, nbits = 0; u64 acc = 0;
             auto put = [&](u32 v, u32 nb) {
                 acc |= (u64)v << nbits; nbits += nb;
-                if (nbits >= 32) { L.hdr[word++] = (u32)acc; acc >>= 32; nbits -= 32; }
+                if (nbits >= 32) { atomicOr(&L.hdr[word++], (u32)acc); acc >>= 32; nbits -= 32; }
             };
             int ncl = 19;
             while (ncl > 4 && L.l_cl[order[ncl - 1]] == 0) --ncl;
             put(1u | 2u << 1, 3);                                   // BFINAL = 1, BTYPE = 10 (dynamic)
             put(L.vars[V_NLIT] - 257, 5); put(L.vars[V_NDIST] - 1, 5); put((u32)ncl - 4, 4);
             for (int i = 0; i < ncl; ++i) put(L.l_cl[order[i]], 3);
-            const int ns = (int)L.vars[V_NCLSYM];
-            for (int i = 0; i < ns; ++i) {
-                const u32 sym = L.clsym[i] & 0xffu, extra = L.clsym[i] >> 8;
-                put(L.c_cl[sym], L.l_cl[sym]);
-                if (sym == 16) put(extra, 2); else if (sym == 17) put(extra, 3); else if (sym == 18) put(extra, 7);
+            L.vars[V_HDRBITS] = word * 32 + nbits;                  // so far; the code-length symbols follow
+            if (nbits) atomicOr(&L.hdr[word], (u32)acc);
+        }
+        __syncthreads();
+        {
+            const u32 ns = L.vars[V_NCLSYM], fixed_bits = L.vars[V_HDRBITS];
+            u32 sym = 0, extra = 0, nb = 0;
+            if (tid < ns) {
+                sym = L.clsym[tid] & 0xffu; extra = L.clsym[tid] >> 8;
+                nb = L.l_cl[sym] + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
             }
-            L.vars[V_HDRBITS] = word * 32 + nbits;
-            if (nbits) L.hdr[word] = (u32)acc;
+            u32 sym_bits;
+            const u32 off = block_scan(L, nb, &sym_bits);
+            if (tid < ns) {
+                BitSink bs;
+                bs.start(L.hdr, fixed_bits + off);
+                bs.put(L.c_cl[sym], L.l_cl[sym]);
+                if (sym == 16) bs.put(extra, 2); else if (sym == 17) bs.put(extra, 3); else if (sym == 18) bs.put(extra, 7);
+                bs.finish();
+            }
+            __syncthreads();
+            if (tid == 0) L.vars[V_HDRBITS] = fixed_bits + sym_bits;
         }
         __syncthreads();
         lap(5);
@@ -770,6 +812,7 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
         if (hipMemcpy(p, c->d_prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess && c->n_blocks) {
             fprintf(stderr, "mgx_bgzf cycles per block: load %llu, match %llu, parse+crc %llu, tokens %llu, huffman %llu, header %llu, emit %llu\n", p[0] / c->n_blocks,
                     p[1] / c->n_blocks, p[2] / c->n_blocks, p[3] / c->n_blocks, p[4] / c->n_blocks, p[5] / c->n_blocks, p[6] / c->n_blocks);
+            fprintf(stderr, "   literal/length code: setup %llu, rank %llu, merge %llu, depths %llu, codes %llu\n", p[8] / c->n_blocks, p[9] / c->n_blocks, p[10] / c->n_blocks, p[11] / c->n_blocks, p[12] / c->n_blocks);
         }
         (void)hipFree(c->d_prof);
     }
