@@ -9,5 +9,5 @@ from .native import MgxError, lib_path, load  # noqa: F401
 from .pairhmm import PairHMMEngine, PairHMMBatch, PairHMMQueue  # noqa: F401
 from .sortdedup import SortDedupEngine, Routed  # noqa: F401
 from .smithwaterman import SmithWatermanEngine  # noqa: F401
-from .bgzf import BgzfCompressor, BgzfBatch  # noqa: F401
+from .bgzf import BgzfCompressor, BgzfBatch, BgzfStore  # noqa: F401
 from . import pairhmm, sortdedup, smithwaterman, bgzf, synth  # noqa: F401

@@ -86,3 +86,44 @@ class BgzfBatch:
         if self.b:
             self.lib.mgx_bgzf_batch_destroy(self.comp.h, self.b)
             self.b = None
+
+
+class BgzfStore:
+    """mgx_bgzf_store_t: records resident in HBM (put), emitted as a sorted, duplicate-marked BGZF stream (emit)."""
+
+    def __init__(self, comp):
+        self.comp = comp
+        self.lib = comp.lib
+        h = C.c_void_p()
+        native.check(self.lib.mgx_bgzf_store_create(comp.h, C.byref(h)))
+        self.h = h
+
+    def put(self, data):
+        data = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        addr = C.c_uint64()
+        native.check(self.lib.mgx_bgzf_store_put(self.h, _ptr(data), len(data), C.byref(addr)))
+        return int(addr.value)
+
+    def emit(self, order, dup, addr, length):
+        """Returns (all blocks back to back as bytes, compressed offset of every block, uoff[n + 1])."""
+        order = np.ascontiguousarray(order, dtype=np.uint32); dup = np.ascontiguousarray(dup, dtype=np.uint8)
+        addr = np.ascontiguousarray(addr, dtype=np.uint64); length = np.ascontiguousarray(length, dtype=np.uint32)
+        n = len(order)
+        uoff = np.zeros(n + 1, dtype=np.uint64)
+        parts, block_at = [], []
+        total = [0]
+
+        def sink(_user, blocks, n_bytes, n_blocks, block_off):
+            parts.append(C.string_at(blocks, n_bytes))
+            oo = np.ctypeslib.as_array(C.cast(block_off, C.POINTER(C.c_uint64)), shape=(n_blocks + 1,))
+            block_at.extend(int(total[0] + x) for x in oo[:n_blocks])
+            total[0] += int(n_bytes)
+            return 0
+        cb = native.BGZF_SINK(sink)
+        native.check(self.lib.mgx_bgzf_store_emit(self.h, n, _ptr(order), _ptr(dup), _ptr(addr), _ptr(length), cb, None, _ptr(uoff)))
+        return b"".join(parts), np.array(block_at + [total[0]], dtype=np.uint64), uoff
+
+    def close(self):
+        if self.h:
+            self.lib.mgx_bgzf_store_destroy(self.h)
+            self.h = None

@@ -23,12 +23,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -739,6 +741,70 @@ __global__ __launch_bounds__(256) void k_bgzf_pack(const u8* slots, const u32* s
     if (threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
 }
 
+// ---- the record store: records resident in HBM, emitted in sorted order ------------------------------------------
+constexpr u32 kScanTile = 4096;
+// slen[q] = 4 + len[order[q]] summed per tile of 4096 records
+__global__ __launch_bounds__(256) void k_store_tile_sums(const u32* order, const u32* len, u64 n, u64* tile_sum) {
+    __shared__ u64 part[256];
+    const u64 base = (u64)blockIdx.x * kScanTile;
+    u64 s = 0;
+    for (u32 i = threadIdx.x; i < kScanTile; i += 256) { const u64 q = base + i; if (q < n) s += 4u + len[order[q]]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) { if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = part[0];
+}
+__global__ __launch_bounds__(1024) void k_store_scan_tiles(u64* tile_sum, u32 n_tiles, u64* total) {      // one workgroup, in place, exclusive
+    __shared__ u64 part[1024];
+    const u32 per = (n_tiles + 1023) / 1024;
+    const u32 lo = min(n_tiles, threadIdx.x * per), hi = min(n_tiles, lo + per);
+    u64 s = 0;
+    for (u32 i = lo; i < hi; ++i) s += tile_sum[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; ++i) { const u64 v = part[i]; part[i] = run; run += v; } *total = run; }
+    __syncthreads();
+    u64 run = part[threadIdx.x];
+    for (u32 i = lo; i < hi; ++i) { const u64 v = tile_sum[i]; tile_sum[i] = run; run += v; }
+}
+// uoff[q] = offset of record q (its block_size field) in the uncompressed stream
+__global__ __launch_bounds__(256) void k_store_offsets(const u32* order, const u32* len, u64 n, const u64* tile_base, u64* uoff) {
+    __shared__ u64 part[256];
+    const u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * 16u;
+    u32 l[16];
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const u64 q = base + i; l[i] = q < n ? 4u + len[order[q]] : 0u; s += l[i]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 run = tile_base[blockIdx.x]; for (int i = 0; i < 256; ++i) { const u64 v = part[i]; part[i] = run; run += v; } }
+    __syncthreads();
+    u64 run = part[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const u64 q = base + i; if (q < n) uoff[q] = run; run += l[i]; }
+}
+// One wavefront per record q in [q0, q1): block_size + bytes to their place in the window [win0, win0 + win_bytes) of the
+// stream; a duplicate gets FLAG |= 0x400 (byte 15 of the record, bit 2) on the way.
+__global__ __launch_bounds__(256) void k_store_gather(const u64* addr, const u32* len, const u32* order, const u8* dup, const u64* uoff,
+                                                      u64 q0, u64 q1, u64 win0, u64 win_bytes, u8* dst) {
+    const u64 q = q0 + (u64)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (q >= q1) return;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 r = order[q];
+    const u32 n = len[r];
+    const u8* src = reinterpret_cast<const u8*>(addr[r]);
+    const u64 at = uoff[q];
+    const bool is_dup = dup[r] != 0;
+    for (u32 i = lane; i < n + 4u; i += 64u) {
+        const u64 o = at + i;
+        if (o < win0 || o >= win0 + win_bytes) continue;
+        u8 v;
+        if (i < 4) v = (u8)(n >> (8 * i));
+        else { v = src[i - 4]; if (is_dup && i == 4u + 15u) v |= 0x04; }
+        dst[o - win0] = v;
+    }
+}
+
 }  // namespace
 
 struct mgx_bgzf {
@@ -861,7 +927,10 @@ int mgx_bgzf_batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_bloc
 uint8_t* mgx_bgzf_batch_input(mgx_bgzf_batch_t* b) { return b ? b->h_in : nullptr; }
 uint64_t* mgx_bgzf_batch_offsets(mgx_bgzf_batch_t* b) { return b ? b->h_off : nullptr; }
 
-int mgx_bgzf_batch_submit(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, uint32_t n_blocks) {
+static int batch_submit(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, uint32_t n_blocks, bool input_resident);
+int mgx_bgzf_batch_submit(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, uint32_t n_blocks) { return batch_submit(c, b, n_blocks, false); }
+// input_resident: the batch's device input buffer was filled by a kernel on the context's stream (the record store)
+static int batch_submit(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, uint32_t n_blocks, bool input_resident) {
     if (!c || !b) { set_error("NULL argument"); return -EINVAL; }
     if (n_blocks > b->max_blocks) { set_error("%u blocks in a batch made for %u", n_blocks, b->max_blocks); return -EINVAL; }
     if (b->h_off[0] != 0) { set_error("offsets[0] must be 0"); return -EINVAL; }
@@ -877,7 +946,7 @@ int mgx_bgzf_batch_submit(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, uint32_t n_blocks)
     b->n_blocks = n_blocks; b->n_in = n_in; b->submitted = true;
     if (n_blocks == 0) { b->h_out_off[0] = 0; return 0; }
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(b->d_in, b->h_in, n_in, hipMemcpyHostToDevice, s));
+    if (!input_resident) HIP_TRY(hipMemcpyAsync(b->d_in, b->h_in, n_in, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->d_off, b->h_off, ((size_t)n_blocks + 1) * sizeof(u64), hipMemcpyHostToDevice, s));
     DeflateArgs a{};
     a.in = b->d_in; a.off = b->d_off; a.n_blocks = n_blocks; a.slots = b->d_slots; a.sizes = b->d_sizes;
@@ -959,6 +1028,131 @@ int mgx_bgzf_compress(mgx_bgzf_t* c, const uint8_t* in, const uint64_t* offsets,
     if (!rc) rc = drain(k);
     if (!rc) rc = drain(k ^ 1);
     for (int i = 0; i < 2; ++i) mgx_bgzf_batch_destroy(c, bt[i]);
+    return rc;
+}
+
+// ---- record store ---------------------------------------------------------------------------------------------------
+struct mgx_bgzf_store {
+    mgx_bgzf* ctx = nullptr;
+    std::mutex mu;
+    std::vector<u8*> chunks;
+    u64 cur_off = 0, cur_cap = 0, total = 0;
+    hipStream_t copy[8] = {};                  // put() copies on these, never on the null stream (which would wait for every blocking stream of the process)
+    std::atomic<unsigned> next_copy{0};
+};
+
+int mgx_bgzf_store_create(mgx_bgzf_t* c, mgx_bgzf_store_t** out) {
+    if (!c || !out) { set_error("NULL argument"); return -EINVAL; }
+    mgx_bgzf_store* st = new (std::nothrow) mgx_bgzf_store;
+    if (!st) { set_error("out of memory"); return -ENOMEM; }
+    st->ctx = c;
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto& sc : st->copy) HIP_TRY(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
+    *out = st;
+    return 0;
+}
+
+void mgx_bgzf_store_destroy(mgx_bgzf_store_t* st) {
+    if (!st) return;
+    (void)hipSetDevice(st->ctx->device);
+    for (u8* p : st->chunks) (void)hipFree(p);
+    for (auto& sc : st->copy) if (sc) (void)hipStreamDestroy(sc);
+    delete st;
+}
+
+int mgx_bgzf_store_put(mgx_bgzf_store_t* st, const uint8_t* bytes, uint64_t n, uint64_t* addr) {
+    if (!st || !addr || (n && !bytes)) { set_error("NULL argument"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(st->ctx->device));
+    u8* dst;
+    {
+        std::lock_guard<std::mutex> g(st->mu);
+        const u64 need = (n + 15) & ~15ull;
+        if (st->cur_off + need > st->cur_cap) {
+            const u64 cap = std::max<u64>(need, 1ull << 30);          // HBM in 1 GB pieces; a put never straddles two
+            u8* p = nullptr;
+            if (hipMalloc((void**)&p, cap) != hipSuccess) { set_error("hipMalloc of %llu bytes for the record store failed (%llu bytes stored)", (unsigned long long)cap, (unsigned long long)st->total); return -ENOMEM; }
+            st->chunks.push_back(p); st->cur_off = 0; st->cur_cap = cap;
+        }
+        dst = st->chunks.back() + st->cur_off;
+        st->cur_off += need; st->total += n;
+    }
+    if (n) {
+        hipStream_t sc = st->copy[st->next_copy.fetch_add(1) % 8u];
+        HIP_TRY(hipMemcpyAsync(dst, bytes, n, hipMemcpyHostToDevice, sc));
+        HIP_TRY(hipStreamSynchronize(sc));
+    }
+    *addr = (uint64_t)(uintptr_t)dst;
+    return 0;
+}
+
+int mgx_bgzf_store_emit(mgx_bgzf_store_t* st, uint64_t n, const uint32_t* order, const uint8_t* dup, const uint64_t* addr, const uint32_t* len,
+                        mgx_bgzf_sink_t sink, void* user, uint64_t* uoff_out) {
+    if (!st || !sink || !uoff_out || (n && (!order || !dup || !addr || !len))) { set_error("NULL argument"); return -EINVAL; }
+    mgx_bgzf* c = st->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    uoff_out[0] = 0;
+    if (n == 0) return 0;
+    if (n > 0xFFFFFFF0ull) { set_error("more than 2^32 records"); return -E2BIG; }
+    hipStream_t s = c->stream;
+    u32 *d_order = nullptr, *d_len = nullptr; u8* d_dup = nullptr; u64 *d_addr = nullptr, *d_uoff = nullptr, *d_tiles = nullptr;
+    const u32 n_tiles = (u32)((n + kScanTile - 1) / kScanTile);
+    int rc = 0;
+    mgx_bgzf_batch_t* bt[3] = {nullptr, nullptr, nullptr};
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d_order); (void)hipFree(d_len); (void)hipFree(d_dup); (void)hipFree(d_addr); (void)hipFree(d_uoff); (void)hipFree(d_tiles);
+        for (auto* b : bt) if (b) mgx_bgzf_batch_destroy(c, b);
+    };
+#define STORE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); cleanup(); return -EIO; } } while (0)
+    STORE_TRY(hipMalloc((void**)&d_order, n * sizeof(u32)));
+    STORE_TRY(hipMalloc((void**)&d_len, n * sizeof(u32)));
+    STORE_TRY(hipMalloc((void**)&d_dup, n));
+    STORE_TRY(hipMalloc((void**)&d_addr, n * sizeof(u64)));
+    STORE_TRY(hipMalloc((void**)&d_uoff, (n + 1) * sizeof(u64)));
+    STORE_TRY(hipMalloc((void**)&d_tiles, ((size_t)n_tiles + 1) * sizeof(u64)));
+    STORE_TRY(hipMemcpyAsync(d_order, order, n * sizeof(u32), hipMemcpyHostToDevice, s));
+    STORE_TRY(hipMemcpyAsync(d_len, len, n * sizeof(u32), hipMemcpyHostToDevice, s));
+    STORE_TRY(hipMemcpyAsync(d_dup, dup, n, hipMemcpyHostToDevice, s));
+    STORE_TRY(hipMemcpyAsync(d_addr, addr, n * sizeof(u64), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_store_tile_sums, dim3(n_tiles), dim3(256), 0, s, d_order, d_len, n, d_tiles);
+    hipLaunchKernelGGL(k_store_scan_tiles, dim3(1), dim3(1024), 0, s, d_tiles, n_tiles, d_uoff + n);
+    hipLaunchKernelGGL(k_store_offsets, dim3(n_tiles), dim3(256), 0, s, d_order, d_len, n, d_tiles, d_uoff);
+    STORE_TRY(hipGetLastError());
+    STORE_TRY(hipMemcpyAsync(uoff_out, d_uoff, (n + 1) * sizeof(u64), hipMemcpyDeviceToHost, s));
+    STORE_TRY(hipStreamSynchronize(s));
+    const u64 total = uoff_out[n];
+    constexpr u32 kPer = 2048;                                    // blocks per batch (134 MB of the stream)
+    const u64 win = (u64)kPer * kMaxIn;
+    const u64 n_win = (total + win - 1) / win;
+    for (int i = 0; i < 3 && !rc && (u64)i < n_win; ++i) rc = mgx_bgzf_batch_create(c, win, kPer, &bt[i]);
+    if (rc) { cleanup(); return rc; }
+    auto collect = [&](u64 k) -> int {
+        const uint8_t* o; const uint64_t* oo;
+        mgx_bgzf_batch_t* b = bt[k % 3];
+        const int r = mgx_bgzf_batch_wait(c, b, &o, &oo);
+        if (r) return r;
+        const int sr = sink(user, o, oo[b->n_blocks], b->n_blocks, oo);
+        if (sr) { set_error("the sink returned %d", sr); return -EIO; }
+        return 0;
+    };
+    u64 q_lo = 0;
+    for (u64 k = 0; k < n_win && !rc; ++k) {
+        if (k >= 3) rc = collect(k - 3);
+        if (rc) break;
+        mgx_bgzf_batch_t* b = bt[k % 3];
+        const u64 w0 = k * win, wb = std::min(win, total - w0);
+        // records that touch [w0, w0 + wb): from the one holding byte w0 to the last one starting before the window's end
+        while (q_lo + 1 <= n && uoff_out[q_lo + 1] <= w0) ++q_lo;
+        const u64 q_hi = (u64)(std::lower_bound(uoff_out + q_lo, uoff_out + n, w0 + wb) - uoff_out);
+        const u32 nb = (u32)((wb + kMaxIn - 1) / kMaxIn);
+        for (u32 i = 0; i <= nb; ++i) b->h_off[i] = std::min<u64>((u64)i * kMaxIn, wb);
+        if (q_hi > q_lo)
+            hipLaunchKernelGGL(k_store_gather, dim3((u32)((q_hi - q_lo + 3) / 4)), dim3(256), 0, s, d_addr, d_len, d_order, d_dup, d_uoff, q_lo, q_hi, w0, wb, b->d_in);
+        rc = batch_submit(c, b, nb, true);
+    }
+    for (u64 k = n_win >= 3 ? n_win - 3 : 0; k < n_win && !rc; ++k) rc = collect(k);
+#undef STORE_TRY
+    cleanup();
     return rc;
 }
 

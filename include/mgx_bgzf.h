@@ -54,6 +54,24 @@ uint64_t mgx_bgzf_bound(uint64_t n_bytes, uint64_t n_blocks);
 int mgx_bgzf_compress(mgx_bgzf_t* ctx, const uint8_t* in, const uint64_t* offsets, uint64_t n_blocks, uint8_t* out,
                       uint64_t out_capacity, uint64_t* out_offsets);
 
+/* ---- Record store: the BAM records live in HBM from ingest to output ------------------------------------------------
+ * What the reference keeps on disk between its passes (LZ4-compressed range partitions, sortmardup/main.cpp:194-227) and
+ * reads back record by record in sorted order (main.cpp:385-397) stays on the device here: put() copies a parser's
+ * records (BAM alignment records WITHOUT their block_size field, any number per call, from any thread) into HBM and says
+ * where they are; emit() writes the stream "block_size, record" for q = 0 .. n-1 in the order given -- FLAG |= 0x400 where
+ * the record is marked duplicate (main.cpp:385-388) --, cuts it every 65 280 bytes (records may span blocks, SAMv1 4.1),
+ * compresses the blocks and hands them to `sink` in order.  uoff[q] (n + 1 entries) is record q's offset in the
+ * uncompressed stream: together with the compressed offsets of the blocks it gives the virtual offsets of the index. */
+typedef struct mgx_bgzf_store mgx_bgzf_store_t;
+typedef int (*mgx_bgzf_sink_t)(void* user, const uint8_t* blocks, uint64_t n_bytes, uint32_t n_blocks, const uint64_t* block_offsets);
+int mgx_bgzf_store_create(mgx_bgzf_t* ctx, mgx_bgzf_store_t** out);
+void mgx_bgzf_store_destroy(mgx_bgzf_store_t* st);
+int mgx_bgzf_store_put(mgx_bgzf_store_t* st, const uint8_t* bytes, uint64_t n_bytes, uint64_t* device_address);
+/* order[q] = index (into addr / len / dup) of the q-th record of the output; addr[i] = device address of record i
+ * (put()'s address plus the record's offset in that call's bytes), len[i] its length */
+int mgx_bgzf_store_emit(mgx_bgzf_store_t* st, uint64_t n, const uint32_t* order, const uint8_t* dup, const uint64_t* addr,
+                        const uint32_t* len, mgx_bgzf_sink_t sink, void* user, uint64_t* uoff);
+
 typedef struct mgx_bgzf_stats {
     uint64_t n_blocks, bytes_in, bytes_out;   /* since create */
     uint64_t n_stored;                        /* blocks emitted as stored (incompressible) */

@@ -143,3 +143,41 @@ def test_bad_arguments_are_errors(comp, pkg):
         comp.compress(data, np.array([0, 70000], dtype=np.uint64))          # a piece over 65280 bytes
     with pytest.raises(pkg.MgxError):
         comp.compress(data, np.array([0, 500, 100], dtype=np.uint64))       # decreasing offsets
+
+
+@pytest.mark.parametrize("n,seed,len_range", [(5000, 11, (40, 500)), (1, 12, (100, 101)), (300, 13, (60000, 140000)), (200000, 14, (180, 420))])
+def test_record_store_emits_the_sorted_marked_stream(comp, pkg, n, seed, len_range):
+    """Records put into HBM in arrival order by several calls, emitted in a random order with random duplicate marks:
+    the inflated stream is block_size + record for every record in that order, FLAG |= 0x400 where marked, cut every
+    65 280 bytes (records longer than a block span several); uoff and the block offsets locate every record."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(len_range[0], len_range[1], n).astype(np.uint32)
+    recs = [rng.integers(0, 256, int(l), dtype=np.uint8) for l in lens]
+    for r in recs:
+        r[15] &= 0xfb                                        # the duplicate bit starts clear, so the expectation is a plain OR
+    store = pkg.BgzfStore(comp)
+    addr = np.zeros(n, dtype=np.uint64)
+    k = 0
+    while k < n:                                             # several put() calls of a few records each
+        m = int(min(n - k, rng.integers(1, max(2, n // 7 + 2))))
+        base = store.put(np.concatenate(recs[k:k + m]))
+        addr[k:k + m] = base + np.concatenate([[0], np.cumsum(lens[k:k + m - 1].astype(np.uint64))]).astype(np.uint64)
+        k += m
+    order = rng.permutation(n).astype(np.uint32)
+    dup = (rng.random(n) < 0.2).astype(np.uint8)
+    blocks, block_at, uoff = store.emit(order, dup, addr, lens)
+    store.close()
+    want = bytearray()
+    for q in range(n):
+        r = recs[order[q]].copy()
+        if dup[order[q]]:
+            r[15] |= 4
+        assert int(uoff[q]) == len(want)
+        want += struct.pack("<I", len(r)) + r.tobytes()
+    assert int(uoff[n]) == len(want)
+    assert gzip.decompress(blocks + pkg.bgzf.EOF_BLOCK) == bytes(want)
+    assert len(block_at) - 1 == (len(want) + 0xff00 - 1) // 0xff00
+    for b in range(0, len(block_at) - 1, max(1, (len(block_at) - 1) // 50)):       # every block is where block_at says and holds its 65 280 bytes
+        blk = blocks[int(block_at[b]):int(block_at[b + 1])]
+        d = zlib.decompressobj(-15)
+        assert d.decompress(blk[18:-8]) + d.flush() == bytes(want[b * 0xff00:(b + 1) * 0xff00])
