@@ -209,6 +209,89 @@ struct RefIndex {
     uint64_t off_beg = ~0ull, off_end = 0, n_mapped = 0, n_unmapped = 0;
 };
 
+// The BAI of the records in output order; voff(k, &vbeg, &vend) gives record k's virtual offsets (called with growing k).
+template <typename VOff>
+bool write_bai(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs, VOff&& voff, std::string* err) {
+    std::vector<RefIndex> idx(hdr.ref_name.size());
+    uint64_t n_no_coor = 0;
+    int32_t last_tid = -2; uint32_t last_bin = 0; std::vector<std::pair<uint64_t, uint64_t>>* last_chunks = nullptr;
+    for (size_t k = 0; k < recs.size(); ++k) {
+        const RecordRef& r = recs[k];
+        uint64_t vb, ve;
+        voff(k, &vb, &ve);
+        if (r.tid < 0 || (size_t)r.tid >= idx.size()) { ++n_no_coor; continue; }
+        RefIndex& ri = idx[r.tid];
+        const int64_t beg = std::max<int64_t>(r.beg, 0), end = std::max<int64_t>(r.end, beg + 1);
+        // the records are coordinate-sorted: neighbours almost always share their bin, so the map is asked once per run
+        const uint32_t bin = (uint32_t)reg2bin(beg, end);
+        if (r.tid != last_tid || bin != last_bin) { last_chunks = &ri.bins[bin]; last_tid = r.tid; last_bin = bin; }
+        auto& chunks = *last_chunks;
+        if (!chunks.empty() && chunks.back().second == vb) chunks.back().second = ve;   // contiguous: extend
+        else chunks.emplace_back(vb, ve);
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+        for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == 0 || vb < ri.linear[w]) ri.linear[w] = vb;
+        ri.off_beg = std::min(ri.off_beg, vb); ri.off_end = std::max(ri.off_end, ve);
+        if (r.mapped) ++ri.n_mapped; else ++ri.n_unmapped;
+    }
+    std::vector<uint8_t> bai;
+    bai.insert(bai.end(), {'B', 'A', 'I', 1});
+    put<int32_t>(bai, (int32_t)idx.size());
+    for (RefIndex& ri : idx) {
+        const bool any = !ri.bins.empty();
+        put<int32_t>(bai, (int32_t)(ri.bins.size() + (any ? 1 : 0)));
+        for (auto& kv : ri.bins) {
+            put<uint32_t>(bai, kv.first);
+            put<int32_t>(bai, (int32_t)kv.second.size());
+            for (auto& c : kv.second) { put<uint64_t>(bai, c.first); put<uint64_t>(bai, c.second); }
+        }
+        if (any) {                                  // metadata pseudo-bin
+            put<uint32_t>(bai, 37450u); put<int32_t>(bai, 2);
+            put<uint64_t>(bai, ri.off_beg); put<uint64_t>(bai, ri.off_end);
+            put<uint64_t>(bai, ri.n_mapped); put<uint64_t>(bai, ri.n_unmapped);
+        }
+        // empty windows inherit the previous non-empty offset, as htslib's index does
+        uint64_t last = 0;
+        for (auto& v : ri.linear) { if (v == 0) v = last; else last = v; }
+        put<int32_t>(bai, (int32_t)ri.linear.size());
+        for (uint64_t v : ri.linear) put<uint64_t>(bai, v);
+    }
+    put<uint64_t>(bai, n_no_coor);
+    FILE* f = fopen((path + ".bai").c_str(), "wb");
+    if (!f) { *err = "cannot open " + path + ".bai"; return false; }
+    bool ok = fwrite(bai.data(), 1, bai.size(), f) == bai.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { *err = "short write to " + path + ".bai"; return false; }
+    return true;
+}
+
+// BAM header (magic, text, reference table) as the bytes of the first BGZF blocks
+std::vector<uint8_t> header_bytes(const samtext::Header& hdr) {
+    std::vector<uint8_t> head;
+    head.insert(head.end(), {'B', 'A', 'M', 1});
+    put<int32_t>(head, (int32_t)hdr.text.size());
+    head.insert(head.end(), hdr.text.begin(), hdr.text.end());
+    put<int32_t>(head, (int32_t)hdr.ref_name.size());
+    for (size_t i = 0; i < hdr.ref_name.size(); ++i) {
+        put<int32_t>(head, (int32_t)hdr.ref_name[i].size() + 1);
+        head.insert(head.end(), hdr.ref_name[i].begin(), hdr.ref_name[i].end());
+        head.push_back(0);
+        put<int32_t>(head, (int32_t)hdr.ref_len[i]);
+    }
+    return head;
+}
+
+bool pwrite_all(int fd, const uint8_t* p, size_t len, uint64_t at) {
+    while (len) {
+        const ssize_t w = pwrite(fd, p, len, (off_t)at);
+        if (w <= 0) { if (w < 0 && errno == EINTR) continue; return false; }
+        p += w; len -= (size_t)w; at += (uint64_t)w;
+    }
+    return true;
+}
+
+const uint8_t kEofBlock[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
 }  // namespace
 
 int reg2bin(int64_t beg, int64_t end) {
@@ -379,60 +462,131 @@ bool write_bam(const std::string& path, const samtext::Header& hdr, const std::v
     if (!ok) { *err = "short write to " + path; return false; }
 
     // ---- BAI (merge of the per-slice offsets, the job of the reference's merge_index)
-    std::vector<RefIndex> idx(hdr.ref_name.size());
-    uint64_t n_no_coor = 0;
-    int32_t last_tid = -2; uint32_t last_bin = 0; std::vector<std::pair<uint64_t, uint64_t>>* last_chunks = nullptr;
-    for (size_t s = 0; s < n_slices; ++s)
-        for (size_t k = lo[s]; k < lo[s + 1]; ++k) {
-            const RecordRef& r = recs[k];
-            const uint64_t vb = rebase(slices[s].vbeg[k - lo[s]], base[s]), ve = rebase(slices[s].vend[k - lo[s]], base[s]);
-            if (r.tid < 0 || (size_t)r.tid >= idx.size()) { ++n_no_coor; continue; }
-            RefIndex& ri = idx[r.tid];
-            const int64_t beg = std::max<int64_t>(r.beg, 0), end = std::max<int64_t>(r.end, beg + 1);
-            // the records are coordinate-sorted: neighbours almost always share their bin, so the map is asked once per run
-            const uint32_t bin = (uint32_t)reg2bin(beg, end);
-            if (r.tid != last_tid || bin != last_bin) { last_chunks = &ri.bins[bin]; last_tid = r.tid; last_bin = bin; }
-            auto& chunks = *last_chunks;
-            if (!chunks.empty() && chunks.back().second == vb) chunks.back().second = ve;   // contiguous: extend
-            else chunks.emplace_back(vb, ve);
-            const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
-            if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
-            for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == 0 || vb < ri.linear[w]) ri.linear[w] = vb;
-            ri.off_beg = std::min(ri.off_beg, vb); ri.off_end = std::max(ri.off_end, ve);
-            if (r.mapped) ++ri.n_mapped; else ++ri.n_unmapped;
-        }
-    std::vector<uint8_t> bai;
-    bai.insert(bai.end(), {'B', 'A', 'I', 1});
-    put<int32_t>(bai, (int32_t)idx.size());
-    for (RefIndex& ri : idx) {
-        const bool any = !ri.bins.empty();
-        put<int32_t>(bai, (int32_t)(ri.bins.size() + (any ? 1 : 0)));
-        for (auto& kv : ri.bins) {
-            put<uint32_t>(bai, kv.first);
-            put<int32_t>(bai, (int32_t)kv.second.size());
-            for (auto& c : kv.second) { put<uint64_t>(bai, c.first); put<uint64_t>(bai, c.second); }
-        }
-        if (any) {                                  // metadata pseudo-bin
-            put<uint32_t>(bai, 37450u); put<int32_t>(bai, 2);
-            put<uint64_t>(bai, ri.off_beg); put<uint64_t>(bai, ri.off_end);
-            put<uint64_t>(bai, ri.n_mapped); put<uint64_t>(bai, ri.n_unmapped);
-        }
-        // empty windows inherit the previous non-empty offset, as htslib's index does
-        uint64_t last = 0;
-        for (auto& v : ri.linear) { if (v == 0) v = last; else last = v; }
-        put<int32_t>(bai, (int32_t)ri.linear.size());
-        for (uint64_t v : ri.linear) put<uint64_t>(bai, v);
-    }
-    put<uint64_t>(bai, n_no_coor);
-    stamp("index built");
+    size_t cur_slice = 0;
+    auto voff = [&](size_t k, uint64_t* vb, uint64_t* ve) {
+        while (k >= lo[cur_slice + 1]) ++cur_slice;          // k only grows
+        *vb = rebase(slices[cur_slice].vbeg[k - lo[cur_slice]], base[cur_slice]);
+        *ve = rebase(slices[cur_slice].vend[k - lo[cur_slice]], base[cur_slice]);
+    };
+    const bool iok = write_bai(path, hdr, recs, voff, err);
+    stamp("index written");
+    return iok;
+}
 
-    // ---- the index file
-    FILE* f = fopen((path + ".bai").c_str(), "wb");
-    if (!f) { *err = "cannot open " + path + ".bai"; return false; }
-    ok = fwrite(bai.data(), 1, bai.size(), f) == bai.size();
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) { *err = "short write to " + path + ".bai"; return false; }
-    return true;
+
+// The records live in HBM (mgx_bgzf_store): recs[k].blob is a DEVICE address.  The device gathers them in output order,
+// marks the duplicates, cuts the stream every 65 280 bytes and compresses it; this thread writes the blocks as they come
+// back and keeps the compressed position of every block for the index.
+bool write_bam_store(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs, void* bgzf_ctx, void* store,
+                     int threads, std::string* err) {
+    const bool trace = getenv("MGX_CLI_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace) fprintf(stderr, "  write_bam_store %-22s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    mgx_bgzf_t* ctx = (mgx_bgzf_t*)bgzf_ctx;
+    const std::vector<uint8_t> head = header_bytes(hdr);
+    std::vector<uint8_t> file;
+    {
+        std::vector<uint64_t> off;
+        for (size_t o = 0; o < head.size(); o += kBlockIn) off.push_back(o);
+        off.push_back(head.size());
+        std::vector<uint64_t> out_off(off.size());
+        file.resize(mgx_bgzf_bound(head.size(), off.size() - 1));
+        if (mgx_bgzf_compress(ctx, head.data(), off.data(), off.size() - 1, file.data(), file.size(), out_off.data())) { *err = mgx_last_error(); return false; }
+        file.resize(out_off.back());
+    }
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { *err = "cannot open " + path; return false; }
+    bool ok = pwrite_all(fd, file.data(), file.size(), 0);
+    const size_t n = recs.size();
+    std::vector<uint32_t> order(n), len(n); std::vector<uint8_t> dup(n); std::vector<uint64_t> addr(n), uoff(n + 1);
+    {
+        std::vector<std::thread> gang;
+        const size_t T = (size_t)std::max(1, std::min(threads, 16));
+        for (size_t t = 0; t < T; ++t)
+            gang.emplace_back([&, t]() {
+                for (size_t q = n * t / T, e = n * (t + 1) / T; q < e; ++q) {
+                    order[q] = (uint32_t)q; len[q] = recs[q].len; dup[q] = recs[q].set_dup; addr[q] = (uint64_t)(uintptr_t)recs[q].blob;
+                }
+            });
+        for (auto& th : gang) th.join();
+    }
+    stamp("arrays ready");
+    // The sink must be done with a batch's bytes when it returns, and the device should not wait for the file: four
+    // helpers each copy a quarter of the batch into a buffer of their own (the sink returns once the copies are made)
+    // and then write it in place while the device works on the next batches.
+    struct Helper {
+        std::thread th; std::mutex mu; std::condition_variable cv;
+        const uint8_t* src = nullptr; uint64_t n = 0, at = 0; int state = 0;      // 0 idle, 1 job posted, 2 copied (writing), -1 quit
+        std::vector<uint8_t> buf; bool ok = true;
+    };
+    struct Sink { int fd; uint64_t at; std::vector<uint64_t> block_at; Helper h[4]; } sk;
+    sk.fd = fd; sk.at = file.size();
+    for (Helper& h : sk.h)
+        h.th = std::thread([&h, fd]() {
+            for (;;) {
+                std::unique_lock<std::mutex> lk(h.mu);
+                h.cv.wait(lk, [&] { return h.state == 1 || h.state == -1; });
+                if (h.state == -1) return;
+                if (h.buf.size() < h.n) h.buf.resize(h.n);
+                memcpy(h.buf.data(), h.src, h.n);
+                h.state = 2;
+                h.cv.notify_all();
+                lk.unlock();
+                const bool w = pwrite_all(fd, h.buf.data(), h.n, h.at);
+                lk.lock();
+                if (!w) h.ok = false;
+                h.state = 0;
+                h.cv.notify_all();
+            }
+        });
+    auto sink = [](void* user, const uint8_t* blocks, uint64_t n_bytes, uint32_t n_blocks, const uint64_t* block_off) -> int {
+        Sink* k = (Sink*)user;
+        for (uint32_t i = 0; i < n_blocks; ++i) k->block_at.push_back(k->at + block_off[i]);
+        for (int t = 0; t < 4; ++t) {
+            Helper& h = k->h[t];
+            const uint64_t lo = n_bytes * t / 4, hi = n_bytes * (t + 1) / 4;
+            std::unique_lock<std::mutex> lk(h.mu);
+            h.cv.wait(lk, [&] { return h.state == 0; });          // its previous quarter is on disk
+            h.src = blocks + lo; h.n = hi - lo; h.at = k->at + lo; h.state = 1;
+            h.cv.notify_all();
+        }
+        bool ok = true;
+        for (int t = 0; t < 4; ++t) {
+            Helper& h = k->h[t];
+            std::unique_lock<std::mutex> lk(h.mu);
+            h.cv.wait(lk, [&] { return h.state != 1; });          // copied: the batch's buffer may be reused
+            ok = ok && h.ok;
+        }
+        if (!ok) return 1;
+        k->at += n_bytes;
+        return 0;
+    };
+    const int emit_rc = mgx_bgzf_store_emit((mgx_bgzf_store_t*)store, n, order.data(), dup.data(), addr.data(), len.data(), sink, &sk, uoff.data());
+    bool helpers_ok = true;
+    for (Helper& h : sk.h) {
+        { std::unique_lock<std::mutex> lk(h.mu); h.cv.wait(lk, [&] { return h.state == 0; }); h.state = -1; h.cv.notify_all(); }
+        h.th.join();
+        helpers_ok = helpers_ok && h.ok;
+    }
+    if (emit_rc || !helpers_ok) {
+        *err = helpers_ok ? std::string("device: ") + mgx_last_error() : "short write to " + path;
+        close(fd);
+        return false;
+    }
+    stamp("stream written");
+    sk.block_at.push_back(sk.at);                    // the position after the last block: virtual offsets at the very end
+    ok = ok && pwrite_all(fd, kEofBlock, 28, sk.at);
+    ok = (close(fd) == 0) && ok;
+    if (!ok) { *err = "short write to " + path; return false; }
+    auto voff = [&](size_t k, uint64_t* vb, uint64_t* ve) {
+        *vb = (sk.block_at[uoff[k] / kBlockIn] << 16) | (uoff[k] % kBlockIn);
+        *ve = (sk.block_at[uoff[k + 1] / kBlockIn] << 16) | (uoff[k + 1] % kBlockIn);
+    };
+    const bool iok = write_bai(path, hdr, recs, voff, err);
+    stamp("index written");
+    return iok;
 }
 
 }  // namespace bamout

@@ -34,4 +34,10 @@ struct RecordRef {              // one record of the output, in output order
 bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
                int threads, int level, int device, std::string* err);
 
+// The same with the records resident in HBM: recs[k].blob is the DEVICE address mgx_bgzf_store_put() returned for the
+// record; bgzf_ctx / store are the mgx_bgzf_t* / mgx_bgzf_store_t* that hold them (include/mgx_bgzf.h).  The device gathers
+// the records in output order, sets the duplicate flags, cuts and compresses the stream; the host writes blocks and index.
+bool write_bam_store(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs, void* bgzf_ctx, void* store,
+                     int threads, std::string* err);
+
 }  // namespace bamout

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "bam_writer.h"
+#include "../../../include/mgx_bgzf.h"
 #include "mgx_pairhmm.h"       // mgx_last_error
 #include "mgx_sortdedup.h"
 #include "sam_text.h"
@@ -63,6 +64,7 @@ struct Chunk {                       // one parsed + packed slice
     std::vector<char> qname; std::vector<uint64_t> qname_off{0};
     std::vector<uint8_t> blob; std::vector<uint64_t> blob_off{0};      // BAM bytes per record (kept until the output is written)
     std::vector<mgx_rec_t> recs; std::vector<uint32_t> input_index;   // arrival order inside the slice
+    uint64_t dev_base = 0;               // -z device: where the slice's BAM bytes are in HBM (blob is dropped then)
     std::string err;
 };
 
@@ -133,7 +135,7 @@ int main(int argc, char** argv) {
     const char* in_path = nullptr; const char* out_path = nullptr;
     int threads = (int)std::thread::hardware_concurrency();
     int device = 0, level = 6;
-    bool device_deflate = true;
+    enum { kOutDevice, kOutPinned, kOutZlib } out_mode = kOutDevice;
     size_t slice_bytes = 8u << 20;     // 8 MB: 20 M records parse in 1.2 s (32 MB slices: 2.1 s -- fewer, longer tasks per thread)
     int c;
     while ((c = getopt(argc, argv, "I:O:t:d:l:s:z:")) >= 0) {
@@ -143,7 +145,12 @@ int main(int argc, char** argv) {
             case 't': threads = atoi(optarg); break;
             case 'd': device = atoi(optarg); break;          // extension: HIP device ordinal
             case 'l': level = atoi(optarg); break;           // extension: deflate level (with -z zlib)
-            case 'z': device_deflate = strcmp(optarg, "zlib") != 0; break;   // extension: BGZF compressor, "device" (default) or "zlib"
+            case 'z':                                        // extension: where the output is made
+                // device (default): BAM bytes resident in HBM from ingest on, gathered + compressed on the device
+                // pinned: BAM bytes in host memory, gathered by the writer threads into pinned batches, compressed on the device
+                // zlib:   BAM bytes in host memory, zlib at -l level on the writer threads (the reference's way)
+                out_mode = !strcmp(optarg, "zlib") ? kOutZlib : !strcmp(optarg, "pinned") ? kOutPinned : kOutDevice;
+                break;
             case 's': slice_bytes = (size_t)atoll(optarg); break;   // extension: bytes of SAM text per slice
             default: fprintf(stderr, "usage: %s [-I input.sam] [-t num] -O output.bam\n", argv[0]); return 2;
         }
@@ -196,6 +203,8 @@ int main(int argc, char** argv) {
     uint64_t L = 0;
     for (uint64_t x : hdr.ref_len) L += x;
 
+    mgx_bgzf_t* zctx = nullptr; mgx_bgzf_store_t* store = nullptr;
+    if (out_mode == kOutDevice && (mgx_bgzf_create(device, 0, &zctx) || mgx_bgzf_store_create(zctx, &store))) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
     mgx_sortdedup_t* sd = nullptr;
     if (mgx_sortdedup_create(device, 0, &sd)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
     if (mgx_sortdedup_upload_begin(sd, L, file_bytes / 256)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
@@ -232,14 +241,15 @@ int main(int argc, char** argv) {
             if (n && mgx_sortdedup_upload_chunk(sd, base, n, ch->recs.data())) { fail(std::string("GPU: ") + mgx_last_error()); return; }
             for (uint64_t k = 0; k < n; ++k) {
                 const uint32_t src = ch->input_index[k];
-                by_arrival.push_back(Kept{ch->blob.data() + ch->blob_off[src], (uint32_t)(ch->blob_off[src + 1] - ch->blob_off[src]),
+                const uint8_t* where = store ? (const uint8_t*)(uintptr_t)(ch->dev_base + ch->blob_off[src]) : ch->blob.data() + ch->blob_off[src];
+                by_arrival.push_back(Kept{where, (uint32_t)(ch->blob_off[src + 1] - ch->blob_off[src]),
                                           ch->tid[src], (int32_t)ch->pos[src], ch->end[src], (ch->flag[src] & 4) == 0});
             }
             n_total += n;
             std::vector<mgx_rec_t>().swap(ch->recs); std::vector<uint32_t>().swap(ch->input_index);
             std::vector<uint16_t>().swap(ch->flag); std::vector<int32_t>().swap(ch->tid); std::vector<int64_t>().swap(ch->pos);
             std::vector<int32_t>().swap(ch->end); std::vector<uint64_t>().swap(ch->blob_off);
-            kept_chunks.push_back(std::move(ch));
+            if (!store) kept_chunks.push_back(std::move(ch));
             ++next_commit;
         }
     };
@@ -258,6 +268,10 @@ int main(int argc, char** argv) {
             parse_slice(sl.text, hdr, L, ch.get());
             std::string().swap(sl.text);
             if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
+            if (store) {                                    // the slice's BAM bytes go to HBM now and leave host memory
+                if (mgx_bgzf_store_put(store, ch->blob.data(), ch->blob.size(), &ch->dev_base)) { fail(std::string("GPU: ") + mgx_last_error()); return; }
+                std::vector<uint8_t>().swap(ch->blob);
+            }
             std::lock_guard<std::mutex> g(commit_mu);
             ready.emplace(sl.seq, std::move(ch));
             commit_ready();
@@ -330,7 +344,9 @@ int main(int argc, char** argv) {
         for (auto& th : gang) th.join();
     }
     std::string err;
-    if (!bamout::write_bam(out_path, hdr, out, threads, level, device_deflate ? device : -1, &err)) { fprintf(stderr, "write: %s\n", err.c_str()); return 1; }
+    const bool wrote = store ? bamout::write_bam_store(out_path, hdr, out, zctx, store, threads, &err)
+                             : bamout::write_bam(out_path, hdr, out, threads, level, out_mode == kOutPinned ? device : -1, &err);
+    if (!wrote) { fprintf(stderr, "write: %s\n", err.c_str()); return 1; }
     time_stamp("output done");
     // Both files are closed.  What is left is tearing down ~N small records' bookkeeping, the arenas and the HIP runtime --
     // a few tenths of a second at 20 M records that change nothing on disk: leave it to the kernel.

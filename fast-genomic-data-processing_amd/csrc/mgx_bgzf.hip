@@ -24,7 +24,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cerrno>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -896,7 +898,11 @@ void mgx_bgzf_batch_destroy(mgx_bgzf_t* c, mgx_bgzf_batch_t* b) {
     delete b;
 }
 
+static int batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_blocks, bool pinned_input, mgx_bgzf_batch_t** out);
 int mgx_bgzf_batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_blocks, mgx_bgzf_batch_t** out) {
+    return batch_create(c, in_capacity, max_blocks, true, out);
+}
+static int batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_blocks, bool pinned_input, mgx_bgzf_batch_t** out) {
     if (!c || !out) { set_error("NULL argument"); return -EINVAL; }
     *out = nullptr;
     if (max_blocks == 0) { set_error("max_blocks is 0"); return -EINVAL; }
@@ -907,7 +913,7 @@ int mgx_bgzf_batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_bloc
     b->in_cap = in_capacity; b->max_blocks = max_blocks;
     b->out_cap = mgx_bgzf_bound(in_capacity, max_blocks);
     auto fail = [&](const char* what) { set_error("%s failed for a batch of %llu bytes / %u blocks", what, (unsigned long long)in_capacity, max_blocks); mgx_bgzf_batch_destroy(c, b); return -ENOMEM; };
-    if (hipHostMalloc((void**)&b->h_in, in_capacity + 8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
+    if (pinned_input && hipHostMalloc((void**)&b->h_in, in_capacity + 8, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
     if (hipHostMalloc((void**)&b->h_off, ((size_t)max_blocks + 1) * sizeof(u64), hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
     if (hipHostMalloc((void**)&b->h_out, b->out_cap, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
     if (hipHostMalloc((void**)&b->h_out_off, ((size_t)max_blocks + 1) * sizeof(u64), hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc");
@@ -1037,8 +1043,14 @@ struct mgx_bgzf_store {
     std::mutex mu;
     std::vector<u8*> chunks;
     u64 cur_off = 0, cur_cap = 0, total = 0;
-    hipStream_t copy[8] = {};                  // put() copies on these, never on the null stream (which would wait for every blocking stream of the process)
-    std::atomic<unsigned> next_copy{0};
+    // put() stages through pinned buffers of its own (a copy from pageable memory is slow and serialises the callers)
+    // and copies on streams of its own, never on the null stream (which would wait for every blocking stream of the process)
+    static constexpr int kStage = 24;
+    static constexpr size_t kStageBytes = 4u << 20;
+    hipStream_t copy[kStage] = {};
+    u8* stage[kStage] = {};
+    std::mutex stage_mu; std::condition_variable stage_cv;
+    std::vector<int> stage_free;
 };
 
 int mgx_bgzf_store_create(mgx_bgzf_t* c, mgx_bgzf_store_t** out) {
@@ -1047,7 +1059,11 @@ int mgx_bgzf_store_create(mgx_bgzf_t* c, mgx_bgzf_store_t** out) {
     if (!st) { set_error("out of memory"); return -ENOMEM; }
     st->ctx = c;
     HIP_TRY(hipSetDevice(c->device));
-    for (auto& sc : st->copy) HIP_TRY(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
+    for (int i = 0; i < mgx_bgzf_store::kStage; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&st->copy[i], hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void**)&st->stage[i], mgx_bgzf_store::kStageBytes, hipHostMallocDefault));
+        st->stage_free.push_back(i);
+    }
     *out = st;
     return 0;
 }
@@ -1057,6 +1073,7 @@ void mgx_bgzf_store_destroy(mgx_bgzf_store_t* st) {
     (void)hipSetDevice(st->ctx->device);
     for (u8* p : st->chunks) (void)hipFree(p);
     for (auto& sc : st->copy) if (sc) (void)hipStreamDestroy(sc);
+    for (auto& p : st->stage) if (p) (void)hipHostFree(p);
     delete st;
 }
 
@@ -1076,10 +1093,21 @@ int mgx_bgzf_store_put(mgx_bgzf_store_t* st, const uint8_t* bytes, uint64_t n, u
         dst = st->chunks.back() + st->cur_off;
         st->cur_off += need; st->total += n;
     }
-    if (n) {
-        hipStream_t sc = st->copy[st->next_copy.fetch_add(1) % 8u];
-        HIP_TRY(hipMemcpyAsync(dst, bytes, n, hipMemcpyHostToDevice, sc));
-        HIP_TRY(hipStreamSynchronize(sc));
+    for (u64 done = 0; done < n;) {
+        int k;
+        {
+            std::unique_lock<std::mutex> lk(st->stage_mu);
+            st->stage_cv.wait(lk, [&] { return !st->stage_free.empty(); });
+            k = st->stage_free.back(); st->stage_free.pop_back();
+        }
+        const u64 piece = std::min<u64>(mgx_bgzf_store::kStageBytes, n - done);
+        memcpy(st->stage[k], bytes + done, piece);
+        hipError_t e = hipMemcpyAsync(dst + done, st->stage[k], piece, hipMemcpyHostToDevice, st->copy[k]);
+        if (e == hipSuccess) e = hipStreamSynchronize(st->copy[k]);
+        { std::lock_guard<std::mutex> g(st->stage_mu); st->stage_free.push_back(k); }
+        st->stage_cv.notify_one();
+        if (e != hipSuccess) { set_error("copy of %llu bytes to the record store: %s", (unsigned long long)piece, hipGetErrorString(e)); return -EIO; }
+        done += piece;
     }
     *addr = (uint64_t)(uintptr_t)dst;
     return 0;
@@ -1121,17 +1149,26 @@ int mgx_bgzf_store_emit(mgx_bgzf_store_t* st, uint64_t n, const uint32_t* order,
     STORE_TRY(hipMemcpyAsync(uoff_out, d_uoff, (n + 1) * sizeof(u64), hipMemcpyDeviceToHost, s));
     STORE_TRY(hipStreamSynchronize(s));
     const u64 total = uoff_out[n];
-    constexpr u32 kPer = 2048;                                    // blocks per batch (134 MB of the stream)
+    const bool trace = getenv("MGX_BGZF_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_wait = 0, t_sink = 0;
+    if (trace) fprintf(stderr, "  store_emit: arrays on the device, offsets scanned and back: %.3f s\n", now());
+    constexpr u32 kPer = 1024;                                    // blocks per batch (67 MB of the stream)
     const u64 win = (u64)kPer * kMaxIn;
     const u64 n_win = (total + win - 1) / win;
-    for (int i = 0; i < 3 && !rc && (u64)i < n_win; ++i) rc = mgx_bgzf_batch_create(c, win, kPer, &bt[i]);
+    for (int i = 0; i < 3 && !rc && (u64)i < n_win; ++i) rc = batch_create(c, win, kPer, false, &bt[i]);
     if (rc) { cleanup(); return rc; }
+    if (trace) fprintf(stderr, "  store_emit: batches allocated: %.3f s\n", now());
     auto collect = [&](u64 k) -> int {
         const uint8_t* o; const uint64_t* oo;
         mgx_bgzf_batch_t* b = bt[k % 3];
+        const double t0 = now();
         const int r = mgx_bgzf_batch_wait(c, b, &o, &oo);
         if (r) return r;
+        const double t1 = now();
         const int sr = sink(user, o, oo[b->n_blocks], b->n_blocks, oo);
+        t_wait += t1 - t0; t_sink += now() - t1;
         if (sr) { set_error("the sink returned %d", sr); return -EIO; }
         return 0;
     };
@@ -1151,6 +1188,7 @@ int mgx_bgzf_store_emit(mgx_bgzf_store_t* st, uint64_t n, const uint32_t* order,
         rc = batch_submit(c, b, nb, true);
     }
     for (u64 k = n_win >= 3 ? n_win - 3 : 0; k < n_win && !rc; ++k) rc = collect(k);
+    if (trace) fprintf(stderr, "  store_emit: %llu windows done: %.3f s (waiting for the device %.3f s, in the sink %.3f s)\n", (unsigned long long)n_win, now(), t_wait, t_sink);
 #undef STORE_TRY
     cleanup();
     return rc;

@@ -136,7 +136,8 @@ def reg2bin(beg, end):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_templates,threads,slice_bytes,stdin,deflate", [(1200, 4, 0, False, "device"), (150, 1, 0, False, "device"), (1200, 3, 4096, False, "zlib"),
-                                                                          (600, 2, 1500, True, "device"), (9000, 5, 0, False, "device")])
+                                                                          (600, 2, 1500, True, "device"), (9000, 5, 0, False, "device"), (9000, 5, 0, False, "pinned"),
+                                                                          (1200, 3, 4096, False, "pinned")])
 def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads, slice_bytes, stdin, deflate):
     """slice_bytes > 0 forces the streaming ingest to cut the text into many slices (each ending on a queryname-group
     boundary) that are parsed out of order and committed in order; the result must not depend on it."""
@@ -216,15 +217,15 @@ def test_cli_device_and_zlib_deflate_hold_the_same_stream(tmp_path, synth):
     sam = str(tmp_path / "in.sam")
     make_sam(raw, sam)
     streams, sizes = [], []
-    for z in ("device", "zlib"):
+    for z in ("device", "zlib", "pinned"):
         bam = str(tmp_path / f"{z}.bam")
         res = subprocess.run([build_cli(), "-I", sam, "-O", bam, "-t", "4", "-z", z], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
         streams.append(gzip.decompress(open(bam, "rb").read()))
         sizes.append(os.path.getsize(bam))
         assert open(bam, "rb").read()[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
-    assert streams[0] == streams[1]
-    assert sizes[0] < 1.25 * sizes[1]
+    assert streams[0] == streams[1] == streams[2]
+    assert sizes[0] < 1.25 * sizes[1] and sizes[2] < 1.25 * sizes[1]
 
 
 def test_cli_usage_and_build(pkg):

@@ -36,9 +36,10 @@ def run(extra, tag):
     return h.hexdigest(), os.path.getsize(bam)
 
 
-a = run([], "default (8 MB slices, BGZF on the device)")
+a = run([], "default (8 MB slices; -z device: BAM bytes resident in HBM, gathered and compressed on the device)")
 b = run(["-s", str(32 << 20)], "32 MB slices")
 print("BAM size", a[1], "identical output for both slice sizes:", a == b)
+p_ = run(["-z", "pinned"], "-z pinned (BAM bytes in host memory, gathered by the writer threads, compressed on the device)")
 z = run(["-z", "zlib"], "-z zlib (level 6 on the writer threads)")
 print("BAM size with zlib", z[1], "device / zlib = %.3f" % (a[1] / z[1]))
 if len(sys.argv) > 4:
