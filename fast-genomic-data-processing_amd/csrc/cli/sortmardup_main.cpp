@@ -20,6 +20,7 @@
 // There is no CPU fallback: without a HIP device the tool exits with an error.
 #include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -55,7 +56,7 @@ void time_stamp(const char* hint) {
     g_last = now;
 }
 
-struct Slice { uint64_t seq = 0; std::string text; };
+struct Slice { uint64_t seq = 0; std::string text; const char* view = nullptr; size_t view_len = 0; };   // owned text (stdin) or a window of the mapped file
 
 struct Chunk {                       // one parsed + packed slice
     std::vector<uint16_t> flag; std::vector<int32_t> tid; std::vector<int64_t> pos; std::vector<int32_t> end;
@@ -93,10 +94,9 @@ size_t last_group_start(const char* data, size_t size) {
     return group;
 }
 
-void parse_slice(const std::string& text, const samtext::Header& h, uint64_t L_expected, Chunk* c) {
+void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64_t L_expected, Chunk* c) {
     samtext::Record r;
-    const char* data = text.data();
-    size_t off = 0, hi = text.size();
+    size_t off = 0, hi = size;
     while (off < hi) {
         const char* nl = (const char*)memchr(data + off, '\n', hi - off);
         size_t len = nl ? (size_t)(nl - (data + off)) : hi - off;
@@ -171,6 +171,14 @@ int main(int argc, char** argv) {
 #endif
     setvbuf(f, nullptr, _IONBF, 0);                          // read_more() asks for megabytes at a time: no second buffer
 
+    // A regular file is mapped: slices are windows of the mapping, the text is first touched by the parser threads
+    // (stdin, and anything that cannot be mapped, goes through read() and owned slices).
+    const char* map = nullptr; size_t map_size = 0;
+    if (in_path && file_bytes) {
+        void* m = mmap(nullptr, (size_t)file_bytes, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+        if (m != MAP_FAILED) { map = (const char*)m; map_size = (size_t)file_bytes; (void)madvise(m, map_size, MADV_SEQUENTIAL); }
+    }
+
     // ---- header: read until a line that does not start with '@' is complete
     std::string carry;                                       // text read but not yet handed to a parser
     samtext::Header hdr;
@@ -184,7 +192,9 @@ int main(int argc, char** argv) {
             carry.append(buf.data(), got); got_total += got;
         }
     };
-    for (;;) {
+    size_t map_pos = 0;
+    if (map) map_pos = samtext::parse_header(map, map_size, &hdr);
+    else for (;;) {
         // the header is complete once the buffer holds a full line that does not start with '@'
         size_t off = 0; bool body_seen = false;
         while (off < carry.size()) {
@@ -196,7 +206,7 @@ int main(int argc, char** argv) {
         if (body_seen || eof) break;
         read_more(1u << 20);
     }
-    {
+    if (!map) {
         const size_t body = samtext::parse_header(carry.data(), carry.size(), &hdr);
         carry.erase(0, body);
     }
@@ -265,7 +275,8 @@ int main(int argc, char** argv) {
                 cv_room.notify_one();
             }
             std::unique_ptr<Chunk> ch(new Chunk);
-            parse_slice(sl.text, hdr, L, ch.get());
+            if (sl.view) parse_slice(sl.view, sl.view_len, hdr, L, ch.get());
+            else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
             std::string().swap(sl.text);
             if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
             if (store) {                                    // the slice's BAM bytes go to HBM now and leave host memory
@@ -283,7 +294,27 @@ int main(int argc, char** argv) {
     // ---- reader: slices end where a queryname group ends
     uint64_t seq = 0;
     size_t window = slice_bytes;                             // grows only while one queryname group fills the whole window
-    while (!failed.load()) {
+    while (map && !failed.load() && map_pos < map_size) {
+        const size_t limit = std::min(map_size - map_pos, window);
+        size_t cut;
+        if (limit == map_size - map_pos) cut = limit;
+        else {
+            const char* last_nl = (const char*)memrchr(map + map_pos, '\n', limit);
+            cut = last_nl ? last_group_start(map + map_pos, (size_t)(last_nl - (map + map_pos)) + 1) : 0;
+            if (cut == 0) { window *= 2; continue; }
+        }
+        window = slice_bytes;
+        Slice sl;
+        sl.seq = seq++;
+        sl.view = map + map_pos; sl.view_len = cut;
+        map_pos += cut;
+        std::unique_lock<std::mutex> lk(mu);
+        cv_room.wait(lk, [&] { return queue.size() < queue_cap || failed.load(); });
+        if (failed.load()) break;
+        queue.push_back(std::move(sl));
+        cv_work.notify_one();
+    }
+    while (!map && !failed.load()) {
         if (carry.size() < window && !eof) read_more(window - carry.size());
         if (carry.empty() && eof) break;
         size_t cut;
