@@ -521,8 +521,9 @@ bool write_bam_store(const std::string& path, const samtext::Header& hdr, const 
         const uint8_t* src = nullptr; uint64_t n = 0, at = 0; int state = 0;      // 0 idle, 1 job posted, 2 copied (writing), -1 quit
         std::vector<uint8_t> buf; bool ok = true;
     };
-    struct Sink { int fd; uint64_t at; std::vector<uint64_t> block_at; Helper h[4]; } sk;
+    struct Sink { int fd; uint64_t at; std::vector<uint64_t> block_at; std::vector<Helper> h; } sk;
     sk.fd = fd; sk.at = file.size();
+    { const char* e = getenv("MGX_CLI_WRITERS"); const int nh = e ? atoi(e) : 4; sk.h = std::vector<Helper>((size_t)std::max(1, std::min(nh, 32))); }
     for (Helper& h : sk.h)
         h.th = std::thread([&h, fd]() {
             for (;;) {
@@ -544,16 +545,17 @@ bool write_bam_store(const std::string& path, const samtext::Header& hdr, const 
     auto sink = [](void* user, const uint8_t* blocks, uint64_t n_bytes, uint32_t n_blocks, const uint64_t* block_off) -> int {
         Sink* k = (Sink*)user;
         for (uint32_t i = 0; i < n_blocks; ++i) k->block_at.push_back(k->at + block_off[i]);
-        for (int t = 0; t < 4; ++t) {
+        const int nh = (int)k->h.size();
+        for (int t = 0; t < nh; ++t) {
             Helper& h = k->h[t];
-            const uint64_t lo = n_bytes * t / 4, hi = n_bytes * (t + 1) / 4;
+            const uint64_t lo = n_bytes * t / nh, hi = n_bytes * (t + 1) / nh;
             std::unique_lock<std::mutex> lk(h.mu);
             h.cv.wait(lk, [&] { return h.state == 0; });          // its previous quarter is on disk
             h.src = blocks + lo; h.n = hi - lo; h.at = k->at + lo; h.state = 1;
             h.cv.notify_all();
         }
         bool ok = true;
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < nh; ++t) {
             Helper& h = k->h[t];
             std::unique_lock<std::mutex> lk(h.mu);
             h.cv.wait(lk, [&] { return h.state != 1; });          // copied: the batch's buffer may be reused

@@ -275,8 +275,12 @@ int main(int argc, char** argv) {
                 cv_room.notify_one();
             }
             std::unique_ptr<Chunk> ch(new Chunk);
-            if (sl.view) parse_slice(sl.view, sl.view_len, hdr, L, ch.get());
-            else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
+            if (sl.view) {
+                parse_slice(sl.view, sl.view_len, hdr, L, ch.get());
+                // the slice's pages leave this process's resident set (they stay in the page cache)
+                const uintptr_t page = 4096, lo = ((uintptr_t)sl.view + page - 1) & ~(page - 1), hi = ((uintptr_t)sl.view + sl.view_len) & ~(page - 1);
+                if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
+            } else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
             std::string().swap(sl.text);
             if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
             if (store) {                                    // the slice's BAM bytes go to HBM now and leave host memory
