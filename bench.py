@@ -289,7 +289,9 @@ def bgzf_leg(pkg, synth, args, rank, local_rank):
            "compressed_over_input": ratio, "pinned_to_pinned_GBps": n_batches * per * B / dt / 1e9, "blocks_stored": int(st["n_stored"]),
            "inflates_to_input": bool(ok),
            "roofline": {"bound": "hbm", "limiter": "lds-latency", "achieved": alg / kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_bgzf_deflate", "kernel_ms": kernel_ms,
+                        "frac": alg / kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": measured_traffic("k_bgzf_deflate"),
+                        "traffic_source": "offline rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in this run",
+                        "kernel": "k_bgzf_deflate", "kernel_ms": kernel_ms,
                         "kernel_ms_source": "HIP events around the deflate + offsets + pack kernels of a batch, median over the batches",
                         "alg_bytes_per_launch": alg,
                         "note": "entropy coding: serial dependences inside a block (hash chains, Huffman construction, bit offsets) run in "
