@@ -64,9 +64,9 @@ constexpr u32 kPad = 320;                      // zero bytes after the input in 
 constexpr u32 kCrcPoly = 0xEDB88320u;
 constexpr int kNumLL = 286, kNumD = 30, kNumCL = 19;
 constexpr int kAhead = 4;                      // windows whose tokens are fetched ahead of their use (one memory round trip per 16)
-constexpr u32 kScratchPerWg = 65536u + kAhead * 1024u;     // u32 per workgroup: decided matches, then packed tokens, by position
+constexpr u32 kScratchPerWg = 2u * (65536u + kAhead * 1024u);     // the match table by position, then the tokens, densely     // u32 per workgroup: decided matches, then packed tokens, by position
 
-enum { V_OVER = 0, V_NUSED, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
+enum { V_OVER = 0, V_NUSED, V_NTOK, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
 
 struct __attribute__((aligned(16))) Lds {
     u32 buf[(0x10000 + 512) / 4];              // the block's bytes (at the source's alignment), later the output words
@@ -473,6 +473,12 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
 #pragma unroll
             for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) { mask |= 1ull << i; const u32 l = MGX_LEN_AT(i); next += l ? l : 1u; }
             L.mask[tid] = mask;
+            // tokens are stored densely, in position order: chunk t's tokens start at the sum of the earlier chunks' counts
+            u32 all_tokens;
+            const u32 first = block_scan(L, (u32)__builtin_popcountll(mask), &all_tokens);
+            L.cend[tid] = first;
+            if (tid == 0) L.vars[V_NTOK] = all_tokens;
+            __syncthreads();                                // the scan's partial sums are about to be reused by the CRC
         }
 #undef MGX_LEN_AT
         // ---- 5. CRC-32 of the chunk, shifted to the end of the block
@@ -498,7 +504,9 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             L.vars[V_CRC] = c ^ 0xFFFFFFFFu;
         }
         lap(2);
-        // ---- tokens, position-parallel: the token starting at a position (or none) in packed form, and the symbol counts
+        // ---- tokens, position-parallel: the token starting at a position in packed form, stored densely, and the symbol counts
+        u32* const tokd = mat + 65536u + kAhead * 1024u;
+        const u32 n_tok = L.vars[V_NTOK];
         const u32 n_win = (n + kNT - 1) / kNT;
         for (u32 w0 = 0; w0 < n_win; w0 += kAhead) {
             u32 mm[kAhead];
@@ -508,7 +516,8 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             for (int j = 0; j < kAhead; ++j) {
                 const u32 p = (w0 + j) * kNT + tid;
                 u32 t = kTokNone;
-                if (p < n && ((L.mask[p >> 6] >> (p & 63u)) & 1ull)) {
+                const u64 cmask = p < n ? L.mask[p >> 6] : 0ull;
+                if ((cmask >> (p & 63u)) & 1ull) {
                     const u32 len = mm[j] >> 16;
                     if (len) {
                         u32 ls, leb, lev, ds, deb, dev;
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
                         atomicAdd(&L.f_ll[t], 1u);
                     }
                 }
-                if (w0 + j < n_win) mat[p] = t;
+                if (t != kTokNone) tokd[L.cend[p >> 6] + (u32)__builtin_popcountll(cmask & ((1ull << (p & 63u)) - 1ull))] = t;
             }
         }
         __syncthreads();
@@ -636,16 +645,17 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             for (u32 w = tid; w < ((hdr_bits + 31) >> 5); w += kNT) atomicOr(&L.buf[w], L.hdr[w]);
             // bit offset of every (window, wavefront) group of 64 positions: their totals, scanned in position order
             const u32 lane = tid & 63u, wave = tid >> 6;
+            const u32 n_tw = (n_tok + kNT - 1) / kNT;         // windows of 1024 TOKENS from here on
             L.cend[tid] = 0;
             __syncthreads();
-            for (u32 w0 = 0; w0 < n_win; w0 += kAhead) {
+            for (u32 w0 = 0; w0 < n_tw; w0 += kAhead) {
                 u32 t4[kAhead];
 #pragma unroll
-                for (int j = 0; j < kAhead; ++j) t4[j] = mat[(w0 + j) * kNT + tid];
+                for (int j = 0; j < kAhead; ++j) { const u32 i = (w0 + j) * kNT + tid; t4[j] = i < n_tok ? tokd[i] : kTokNone; }
 #pragma unroll
                 for (int j = 0; j < kAhead; ++j) {
-                    const u32 v = wave_last(wave_scan_inclusive(w0 + j < n_win ? token_bits(L, t4[j]) : 0u, OpAdd()));
-                    if (lane == 0 && w0 + j < n_win) L.cend[(w0 + j) * (kNT / 64) + wave] = v;
+                    const u32 v = wave_last(wave_scan_inclusive(token_bits(L, t4[j]), OpAdd()));
+                    if (lane == 0 && w0 + j < n_tw) L.cend[(w0 + j) * (kNT / 64) + wave] = v;
                 }
             }
             __syncthreads();
@@ -654,14 +664,14 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             __syncthreads();
             L.cend[tid] = hdr_bits + group_off;
             __syncthreads();
-            for (u32 w0 = 0; w0 < n_win; w0 += kAhead) {
+            for (u32 w0 = 0; w0 < n_tw; w0 += kAhead) {
                 u32 t4[kAhead];
 #pragma unroll
-                for (int j = 0; j < kAhead; ++j) t4[j] = mat[(w0 + j) * kNT + tid];
+                for (int j = 0; j < kAhead; ++j) { const u32 i = (w0 + j) * kNT + tid; t4[j] = i < n_tok ? tokd[i] : kTokNone; }
 #pragma unroll
                 for (int j = 0; j < kAhead; ++j) {
                     const u32 t = t4[j];
-                    const u32 nb = w0 + j < n_win ? token_bits(L, t) : 0u;
+                    const u32 nb = token_bits(L, t);
                     const u32 inc = wave_scan_inclusive(nb, OpAdd());
                     if (nb) {
                         BitSink s;
