@@ -55,6 +55,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 constexpr u32 kWin = 960;                       // positions per match window: 15 wavefronts extend matches, the 16th feeds them
+constexpr u32 kGrp = 4;                         // match windows between two workgroup barriers
 constexpr int kNT = 1024;                      // threads per workgroup = positions per match window (16 wavefronts: one block per CU, LDS-bound)
 constexpr int kHashBits = 12;
 constexpr u32 kMaxIn = MGX_BGZF_MAX_BLOCK_IN;
@@ -83,7 +84,7 @@ struct __attribute__((aligned(16))) Lds {
     u32 bl_count[16], next_code[16];
     u32 wsum[kNT / 64];
     u64 smask[6];                              // header: which of the (up to 316) code lengths start a run
-    u16 cand[2][kWin];                          // hash candidates (position + 1) of the current and the next window
+    u16 cand[2][kGrp * kWin];                          // hash candidates (position + 1) of the current and the next window
     u32 cend[kNT];                             // parse: where chunk t's last token ends
     u64 mask[kNT];                             // parse: the positions of chunk t that start a token
     u32 fw[288];                               // huff_build's working copy of the counts
@@ -388,19 +389,21 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             for (int k = 0; k < kSteps; ++k) cb[k * 64 + (int)plane] = (u16)c[k];
         };
         __syncthreads();
-        if (tid >= kWin) produce(0, L.cand[0]);
+        // kGrp windows per barrier: a wavefront that meets long matches in one window catches up in the next ones
+        if (tid >= kWin)
+            for (u32 g = 0; g < kGrp; ++g) if (g * kWin < n) produce(g * kWin, L.cand[0] + g * kWin);
         __syncthreads();
-        for (u32 w = 0, base = 0; base < n; ++w, base += kWin) {
-            if (tid >= kWin) {                              // the last wavefront only looks candidates up, one window ahead
-                if (base + kWin < n) produce(base + kWin, L.cand[(w + 1) & 1]);
-                __syncthreads();
-                continue;
-            }
+        for (u32 grp = 0, base0 = 0; base0 < n; ++grp, base0 += kGrp * kWin) {
+          if (tid >= kWin) {                                // the last wavefront only looks candidates up, one group of windows ahead
+            for (u32 g = 0; g < kGrp; ++g) { const u32 b = base0 + (kGrp + g) * kWin; if (b < n) produce(b, L.cand[(grp + 1) & 1] + g * kWin); }
+          } else for (u32 g = 0; g < kGrp; ++g) {
+            const u32 base = base0 + g * kWin;
+            if (base >= n) break;
             const u32 p = base + tid;
             u32 len = 0, dist = 0;
             if (p < n) {
                 const u32 maxlen = min(258u, n - p);
-                const u32 cand = L.cand[w & 1][tid];
+                const u32 cand = L.cand[grp & 1][g * kWin + tid];
                 if (cand) {
                     const u32 q = cand - 1, d = p - q;
                     if (d <= 32768u) {
@@ -427,7 +430,8 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             const u32 len_next = (u32)__builtin_amdgcn_update_dpp(0, (int)len, 0x130, 0xf, 0xf, false);      // wave_shl:1: lane i reads lane i + 1
             if (a.lazy && (tid & 63u) != 63u && len_next > len) len = 0;
             mat[p] = len ? (len << 16 | dist) : 0u;
-            __syncthreads();
+          }
+          __syncthreads();
         }
         lap(1);
 
