@@ -318,6 +318,49 @@ def lib_wait(comp, b):
         raise RuntimeError(comp.lib.mgx_last_error().decode())
 
 
+def cli_leg(pkg, synth, args, rank):
+    """Rows B1-B2, B14 / F3 end to end (widening, not BASELINE.json's `value`): the sortmardup-compatible tool on SAM text of
+    configs[3]'s distribution -- text in, BAM + BAI out -- with the BAM bytes resident in HBM and compressed on the device
+    (`-z device`), and with zlib on the writer threads as the reference does (`-z zlib`).  Rank 0 only."""
+    if rank != 0:
+        return None
+    import shutil, subprocess, tempfile, gzip, hashlib
+    exe = os.path.join(ROOT, "fast-genomic-data-processing_amd", "bin", "sortmardup")
+    if not os.path.exists(exe):
+        return {"skipped": "the CLI is not built (python __graft_entry__.py build)"}
+    d = tempfile.mkdtemp(prefix="mgx_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        n = args.cli_records
+        recs, L = synth.gen_sortdedup_packed_fast(n, 0x5EED0004, threads=host_cores())
+        sam = os.path.join(d, "in.sam")
+        text_bytes = synth.write_sam_from_packed(sam, recs)
+        del recs
+        out = {"metric": "sortmardup CLI end to end, Mrecords/s (SAM text in, coordinate-sorted duplicate-marked BAM + BAI out)",
+               "config": {"workload": "BASELINE.json configs[3] distribution as SAM text", "records": n, "text_bytes": text_bytes, "threads": host_cores()}}
+        digests = {}
+        for mode in ("device", "zlib"):
+            bam = os.path.join(d, mode + ".bam")
+            t0 = time.perf_counter()
+            res = subprocess.run([exe, "-I", sam, "-O", bam, "-t", str(host_cores()), "-z", mode], capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if res.returncode:
+                out[mode] = {"error": res.stderr[-300:]}
+                continue
+            stages = {ln.split(":")[0].strip(): float(ln.split(":")[1].split("s")[0]) for ln in res.stdout.splitlines() if " done: " in ln}
+            h = hashlib.md5()
+            with gzip.open(bam, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            digests[mode] = h.hexdigest()
+            out[mode] = {"value": n / dt / 1e6, "unit": "Mrecords/s", "seconds": dt, "stages_s": stages, "bam_bytes": os.path.getsize(bam)}
+        out["same_uncompressed_stream"] = len(digests) == 2 and digests["device"] == digests["zlib"]
+        out["note"] = ("wall time of the process, text in the page cache; -z device: BAM bytes resident in HBM from ingest on, gathered in sorted "
+                       "order, duplicate-flagged and BGZF-compressed on the device; -z zlib: zlib level 6 on the writer threads")
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def timed_resident(eng, batch, steps, warmup, barrier):
     """W untimed + K timed runs of a resident batch, bracketed by barrier + synchronize.  HIP events are
     recorded on the kernel's own stream around every launch of every run; batch.stats() after the
@@ -445,6 +488,7 @@ def main():
     ap.add_argument("--sort-steps", type=int, default=5)
     ap.add_argument("--sw-pairs", type=int, default=20000, help="Smith-Waterman pairs (row F4 leg; 0 skips it)")
     ap.add_argument("--bgzf-mb", type=int, default=1024, help="MB of BAM bytes through the device BGZF compressor (row F3 leg; 0 skips it)")
+    ap.add_argument("--cli-records", type=int, default=4_000_000, help="records through the sortmardup CLI end to end (0 skips the leg)")
     ap.add_argument("--queue-lanes", type=int, default=0, help="host lanes of the work queue (default: min(8, cores / ranks))")
     ap.add_argument("--no-ragged", action="store_true", help="skip sub-run 2b (ragged lengths)")
     ap.add_argument("--no-regions", action="store_true", help="skip the row-F1 leg (1000 regions of 40 x 25)")
@@ -584,6 +628,7 @@ def main():
         sort_line = sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend)
     sw_line = smithwaterman_leg(pkg, synth, args, rank, local_rank) if args.sw_pairs > 0 else None
     bgzf_line = bgzf_leg(pkg, synth, args, rank, local_rank) if args.bgzf_mb > 0 else None
+    cli_line = cli_leg(pkg, synth, args, rank) if args.cli_records > 0 else None
     mixed_line = mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_over_ranks) if args.mixed else None
     if rank == 0:
         if not args.no_regions:
@@ -596,6 +641,8 @@ def main():
             line["smithwaterman"] = sw_line
         if bgzf_line is not None:
             line["bgzf"] = bgzf_line
+        if cli_line is not None:
+            line["cli"] = cli_line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
