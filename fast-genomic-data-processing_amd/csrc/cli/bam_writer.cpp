@@ -305,24 +305,21 @@ int reg2bin(int64_t beg, int64_t end) {
 }
 
 void encode_record(const samtext::Record& r, std::vector<uint8_t>* out) {
-    std::vector<uint8_t>& a = *out;
-    put<int32_t>(a, r.tid);
-    put<int32_t>(a, r.pos);
-    a.push_back((uint8_t)(r.qname.size() + 1));
-    a.push_back(r.mapq);
-    put<uint16_t>(a, (uint16_t)reg2bin(r.pos, r.end()));
-    put<uint16_t>(a, (uint16_t)r.cigar.size());
-    put<uint16_t>(a, r.flag);
-    put<int32_t>(a, (int32_t)r.l_seq);
-    put<int32_t>(a, r.mtid);
-    put<int32_t>(a, r.mpos);
-    put<int32_t>(a, r.tlen);
-    a.insert(a.end(), r.qname.begin(), r.qname.end());
-    a.push_back(0);
-    for (uint32_t c : r.cigar) put<uint32_t>(a, c);
-    a.insert(a.end(), r.seq4.begin(), r.seq4.end());
-    a.insert(a.end(), r.qual.begin(), r.qual.end());
-    a.insert(a.end(), r.aux.begin(), r.aux.end());
+    const size_t l_qn = r.qname.size() + 1, n_cig = r.cigar.size();
+    const size_t total = 32 + l_qn + 4 * n_cig + r.seq4.size() + r.qual.size() + r.aux.size();
+    const size_t at = out->size();
+    out->resize(at + total);
+    uint8_t* p = out->data() + at;
+    auto w = [&p](const void* src, size_t n) { memcpy(p, src, n); p += n; };
+    const int32_t tid = r.tid, pos = r.pos, l_seq = (int32_t)r.l_seq, mtid = r.mtid, mpos = r.mpos, tlen = r.tlen;
+    const uint16_t bin = (uint16_t)reg2bin(r.pos, r.end()), nc = (uint16_t)n_cig, flag = r.flag;
+    const uint8_t lq = (uint8_t)l_qn, mapq = r.mapq, zero = 0;
+    w(&tid, 4); w(&pos, 4); w(&lq, 1); w(&mapq, 1); w(&bin, 2); w(&nc, 2); w(&flag, 2); w(&l_seq, 4); w(&mtid, 4); w(&mpos, 4); w(&tlen, 4);
+    w(r.qname.data(), r.qname.size()); w(&zero, 1);
+    if (n_cig) w(r.cigar.data(), 4 * n_cig);
+    if (!r.seq4.empty()) w(r.seq4.data(), r.seq4.size());
+    if (!r.qual.empty()) w(r.qual.data(), r.qual.size());
+    if (!r.aux.empty()) w(r.aux.data(), r.aux.size());
 }
 
 bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,

@@ -75,14 +75,29 @@ inline bool next_field(const char*& p, const char* end, const char** f, size_t* 
     return true;
 }
 
+// decimal integer with an optional sign, nothing else in the field (what strtoll accepts, minus leading blanks)
 inline bool to_int(const char* f, size_t n, int64_t* v) {
     if (n == 0 || n > 20) return false;
-    char buf[24];
-    memcpy(buf, f, n); buf[n] = 0;
-    char* e; errno = 0;
-    const long long x = strtoll(buf, &e, 10);
-    if (errno || *e) return false;
-    *v = x;
+    size_t i = 0;
+    const bool neg = f[0] == '-';
+    if (f[0] == '-' || f[0] == '+') i = 1;
+    if (i == n || n - i > 18) {                      // no digit, or close to overflow: the careful way
+        if (i == n) return false;
+        char buf[24];
+        memcpy(buf, f, n); buf[n] = 0;
+        char* e; errno = 0;
+        const long long x = strtoll(buf, &e, 10);
+        if (errno || *e) return false;
+        *v = x;
+        return true;
+    }
+    int64_t x = 0;
+    for (; i < n; ++i) {
+        const unsigned d = (unsigned)(f[i] - '0');
+        if (d > 9) return false;
+        x = x * 10 + (int64_t)d;
+    }
+    *v = neg ? -x : x;
     return true;
 }
 
@@ -107,11 +122,10 @@ bool parse_aux(const char* f, size_t n, std::vector<uint8_t>& a, std::string* er
     a.push_back((uint8_t)f[0]); a.push_back((uint8_t)f[1]);
     const char type = f[3];
     const char* v = f + 5; const size_t vn = n - 5;
-    std::string s(v, vn);
     switch (type) {
         case 'A': a.push_back('A'); a.push_back(vn ? (uint8_t)v[0] : 0); return true;
         case 'i': { int64_t x; if (!to_int(v, vn, &x)) { *err = "bad integer tag"; return false; } put_int_tag(a, x); return true; }
-        case 'f': a.push_back('f'); put<float>(a, strtof(s.c_str(), nullptr)); return true;
+        case 'f': a.push_back('f'); put<float>(a, strtof(std::string(v, vn).c_str(), nullptr)); return true;
         case 'Z': case 'H': a.push_back((uint8_t)type); a.insert(a.end(), v, v + vn); a.push_back(0); return true;
         case 'B': {
             if (vn < 1) { *err = "bad B tag"; return false; }
@@ -140,6 +154,17 @@ bool parse_aux(const char* f, size_t n, std::vector<uint8_t>& a, std::string* er
 
 }  // namespace
 
+namespace {
+// reference name -> index; neighbouring records name the same sequence, so the last hit is tried first
+inline int find_ref(const Header& h, const char* name, size_t len) {
+    static thread_local int last = -1;
+    if (last >= 0 && (size_t)last < h.ref_name.size() && h.ref_name[last].size() == len && memcmp(h.ref_name[last].data(), name, len) == 0) return last;
+    const int k = h.find(name, len);
+    if (k >= 0) last = k;
+    return k;
+}
+}  // namespace
+
 bool parse_record(const char* line, size_t len, const Header& h, Record* r, std::string* err) {
     const char* p = line; const char* end = line + len;
     const char* f[11]; size_t n[11];
@@ -150,7 +175,7 @@ bool parse_record(const char* line, size_t len, const Header& h, Record* r, std:
     if (n[0] == 0 || n[0] > 254) { *err = "bad QNAME length"; return false; }
     if (!to_int(f[1], n[1], &v) || v < 0 || v > 65535) { *err = "bad FLAG"; return false; }
     r->flag = (uint16_t)v;
-    r->tid = (n[2] == 1 && f[2][0] == '*') ? -1 : h.find(f[2], n[2]);
+    r->tid = (n[2] == 1 && f[2][0] == '*') ? -1 : find_ref(h, f[2], n[2]);
     if (r->tid < 0 && !(n[2] == 1 && f[2][0] == '*')) { *err = "RNAME not in the header"; return false; }
     if (!to_int(f[3], n[3], &v)) { *err = "bad POS"; return false; }
     r->pos = (int32_t)v - 1;
@@ -172,7 +197,7 @@ bool parse_record(const char* line, size_t len, const Header& h, Record* r, std:
     }
     if (n[6] == 1 && f[6][0] == '=') r->mtid = r->tid;
     else if (n[6] == 1 && f[6][0] == '*') r->mtid = -1;
-    else { r->mtid = h.find(f[6], n[6]); if (r->mtid < 0) { *err = "RNEXT not in the header"; return false; } }
+    else { r->mtid = find_ref(h, f[6], n[6]); if (r->mtid < 0) { *err = "RNEXT not in the header"; return false; } }
     if (!to_int(f[7], n[7], &v)) { *err = "bad PNEXT"; return false; }
     r->mpos = (int32_t)v - 1;
     if (!to_int(f[8], n[8], &v)) { *err = "bad TLEN"; return false; }
@@ -181,8 +206,11 @@ bool parse_record(const char* line, size_t len, const Header& h, Record* r, std:
     if (n[9] == 1 && f[9][0] == '*') { r->l_seq = 0; r->seq4.clear(); }
     else {
         r->l_seq = (uint32_t)n[9];
-        r->seq4.assign((n[9] + 1) / 2, 0);
-        for (size_t i = 0; i < n[9]; ++i) r->seq4[i >> 1] |= (uint8_t)(nt16[(uint8_t)f[9][i]] << ((~i & 1) << 2));
+        r->seq4.resize((n[9] + 1) / 2);
+        const uint8_t* sq = (const uint8_t*)f[9];
+        size_t k = 0;
+        for (; 2 * k + 1 < n[9]; ++k) r->seq4[k] = (uint8_t)(nt16[sq[2 * k]] << 4 | nt16[sq[2 * k + 1]]);
+        if (n[9] & 1) r->seq4[k] = (uint8_t)(nt16[sq[n[9] - 1]] << 4);
     }
     if (n[10] == 1 && f[10][0] == '*') r->qual.assign(r->l_seq, 0xFF);
     else {

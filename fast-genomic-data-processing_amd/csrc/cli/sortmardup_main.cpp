@@ -20,6 +20,7 @@
 // There is no CPU fallback: without a HIP device the tool exits with an error.
 #include <fcntl.h>
 #include <getopt.h>
+#include <malloc.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -56,7 +57,7 @@ void time_stamp(const char* hint) {
     g_last = now;
 }
 
-struct Slice { uint64_t seq = 0; std::string text; const char* view = nullptr; size_t view_len = 0; };   // owned text (stdin) or a window of the mapped file
+struct Slice { uint64_t seq = 0; std::string text; uint64_t file_off = 0; size_t file_len = 0; bool from_file = false; };   // owned text (stdin) or a range of the input file
 
 struct Chunk {                       // one parsed + packed slice
     std::vector<uint16_t> flag; std::vector<int32_t> tid; std::vector<int64_t> pos; std::vector<int32_t> end;
@@ -66,6 +67,8 @@ struct Chunk {                       // one parsed + packed slice
     std::vector<uint8_t> blob; std::vector<uint64_t> blob_off{0};      // BAM bytes per record (kept until the output is written)
     std::vector<mgx_rec_t> recs; std::vector<uint32_t> input_index;   // arrival order inside the slice
     uint64_t dev_base = 0;               // -z device: where the slice's BAM bytes are in HBM (blob is dropped then)
+    uint64_t arrival_base = 0;           // set at commit: the slice's first arrival index
+    std::vector<struct Kept> kept;       // what the writer needs per record, slice-local arrival order (filled by the parser thread)
     std::string err;
 };
 
@@ -97,6 +100,13 @@ size_t last_group_start(const char* data, size_t size) {
 void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64_t L_expected, Chunk* c) {
     samtext::Record r;
     size_t off = 0, hi = size;
+    {
+        // sized from the text so that the vectors do not grow by doubling (a record is rarely under 100 bytes of text)
+        const size_t est = size / 100 + 16;
+        c->flag.reserve(est); c->tid.reserve(est); c->pos.reserve(est); c->end.reserve(est);
+        c->cigar_off.reserve(est + 1); c->qual_off.reserve(est + 1); c->qname_off.reserve(est + 1); c->blob_off.reserve(est + 1);
+        c->cigar.reserve(est * 2); c->qual.reserve(size / 2); c->qname.reserve(size / 4); c->blob.reserve(size);
+    }
     while (off < hi) {
         const char* nl = (const char*)memchr(data + off, '\n', hi - off);
         size_t len = nl ? (size_t)(nl - (data + off)) : hi - off;
@@ -132,6 +142,11 @@ void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64
 
 int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);   // the three sorts overlap on three streams: keep them on distinct hardware queues
+    // The parser threads allocate and free a slice's arrays (megabytes each) thousands of times: keep them inside the malloc
+    // arenas instead of one mmap / munmap -- and its page faults on fresh zero pages -- per array.
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
     const char* in_path = nullptr; const char* out_path = nullptr;
     int threads = (int)std::thread::hardware_concurrency();
     int device = 0, level = 6;
@@ -171,13 +186,21 @@ int main(int argc, char** argv) {
 #endif
     setvbuf(f, nullptr, _IONBF, 0);                          // read_more() asks for megabytes at a time: no second buffer
 
-    // A regular file is mapped: slices are windows of the mapping, the text is first touched by the parser threads
-    // (stdin, and anything that cannot be mapped, goes through read() and owned slices).
-    const char* map = nullptr; size_t map_size = 0;
-    if (in_path && file_bytes) {
-        void* m = mmap(nullptr, (size_t)file_bytes, PROT_READ, MAP_PRIVATE, fileno(f), 0);
-        if (m != MAP_FAILED) { map = (const char*)m; map_size = (size_t)file_bytes; (void)madvise(m, map_size, MADV_SEQUENTIAL); }
-    }
+    // A regular file is read by the parser threads themselves (pread of their own slice into their own buffer): the
+    // reader only looks at a few KB around every cut to place it on a queryname-group boundary.  (Mapping the file
+    // instead cost 1.8 M page faults per 7 GB and made the ingest time vary by 50 % from run to run.)  stdin goes
+    // through read() and owned slices.
+    const int in_fd = (in_path && file_bytes) ? fileno(f) : -1;
+    const bool map = in_fd >= 0;
+    const size_t map_size = (size_t)file_bytes;
+    auto pread_all = [](int fd, char* dst, size_t n, uint64_t at) -> bool {
+        while (n) {
+            const ssize_t g = pread(fd, dst, n, (off_t)at);
+            if (g <= 0) { if (g < 0 && errno == EINTR) continue; return false; }
+            dst += g; n -= (size_t)g; at += (uint64_t)g;
+        }
+        return true;
+    };
 
     // ---- header: read until a line that does not start with '@' is complete
     std::string carry;                                       // text read but not yet handed to a parser
@@ -193,8 +216,23 @@ int main(int argc, char** argv) {
         }
     };
     size_t map_pos = 0;
-    if (map) map_pos = samtext::parse_header(map, map_size, &hdr);
-    else for (;;) {
+    if (map) {
+        // the header: the file's head, more of it until a line that does not start with '@' is in sight
+        std::vector<char> head;
+        for (size_t want = 1u << 20;; want *= 4) {
+            head.resize(std::min(want, map_size));
+            if (!pread_all(in_fd, head.data(), head.size(), 0)) { fprintf(stderr, "cannot read %s\n", in_path); return 1; }
+            size_t off = 0; bool body_seen = false;
+            while (off < head.size()) {
+                if (head[off] != '@') { body_seen = true; break; }
+                const char* nl = (const char*)memchr(head.data() + off, '\n', head.size() - off);
+                if (!nl) break;
+                off = (size_t)(nl - head.data()) + 1;
+            }
+            if (body_seen || head.size() == map_size) break;
+        }
+        map_pos = samtext::parse_header(head.data(), head.size(), &hdr);
+    } else for (;;) {
         // the header is complete once the buffer holds a full line that does not start with '@'
         size_t off = 0; bool body_seen = false;
         while (off < carry.size()) {
@@ -231,15 +269,19 @@ int main(int argc, char** argv) {
     std::mutex commit_mu;
     std::map<uint64_t, std::unique_ptr<Chunk>> ready;
     uint64_t next_commit = 0, n_total = 0;
-    std::vector<std::unique_ptr<Chunk>> kept_chunks;         // own the BAM bytes
-    std::vector<Kept> by_arrival;
-    if (file_bytes) by_arrival.reserve((size_t)(file_bytes / 256));
+    std::vector<std::unique_ptr<Chunk>> kept_chunks;         // committed slices: their writer records, and (not -z device) the BAM bytes
+    std::vector<Kept> by_arrival;                            // flattened after the ingest
     auto fail = [&](const std::string& msg) {
         std::lock_guard<std::mutex> g(mu);
         if (!failed.exchange(true)) first_error = msg;
         cv_work.notify_all(); cv_room.notify_all();
     };
-    auto commit_ready = [&]() {                              // called with commit_mu held
+    double commit_seconds = 0, upload_seconds = 0;           // serial part of the ingest (MGX_CLI_TRACE)
+    // The in-order commit is the one serial step of the ingest: it only turns slice-local mate indices into arrival
+    // indices and hands the packed records to the upload; what it frees is handed back to die outside the lock.
+    auto commit_ready = [&](std::vector<std::vector<mgx_rec_t>>* trash) {      // called with commit_mu held
+        const auto c0 = clk::now();
+        struct Acc { double* d; clk::time_point t; ~Acc() { *d += std::chrono::duration<double>(clk::now() - t).count(); } } acc{&commit_seconds, c0};
         for (;;) {
             auto it = ready.find(next_commit);
             if (it == ready.end()) return;
@@ -248,22 +290,18 @@ int main(int argc, char** argv) {
             const uint64_t base = n_total, n = ch->recs.size();
             if (base + n >= 0xFFFFFFF0ull) { fail("more than 2^32 records"); return; }
             for (auto& r : ch->recs) if (r.mate != MGX_NO_MATE) r.mate += (uint32_t)base;        // slice-local -> global arrival index
+            const auto u0 = clk::now();
             if (n && mgx_sortdedup_upload_chunk(sd, base, n, ch->recs.data())) { fail(std::string("GPU: ") + mgx_last_error()); return; }
-            for (uint64_t k = 0; k < n; ++k) {
-                const uint32_t src = ch->input_index[k];
-                const uint8_t* where = store ? (const uint8_t*)(uintptr_t)(ch->dev_base + ch->blob_off[src]) : ch->blob.data() + ch->blob_off[src];
-                by_arrival.push_back(Kept{where, (uint32_t)(ch->blob_off[src + 1] - ch->blob_off[src]),
-                                          ch->tid[src], (int32_t)ch->pos[src], ch->end[src], (ch->flag[src] & 4) == 0});
-            }
+            upload_seconds += std::chrono::duration<double>(clk::now() - u0).count();
+            ch->arrival_base = base;
             n_total += n;
-            std::vector<mgx_rec_t>().swap(ch->recs); std::vector<uint32_t>().swap(ch->input_index);
-            std::vector<uint16_t>().swap(ch->flag); std::vector<int32_t>().swap(ch->tid); std::vector<int64_t>().swap(ch->pos);
-            std::vector<int32_t>().swap(ch->end); std::vector<uint64_t>().swap(ch->blob_off);
-            if (!store) kept_chunks.push_back(std::move(ch));
+            trash->emplace_back(std::move(ch->recs));
+            kept_chunks.push_back(std::move(ch));
             ++next_commit;
         }
     };
     auto worker = [&]() {
+        std::vector<char> text_buf;                          // this thread's slice of the input file
         for (;;) {
             Slice sl;
             {
@@ -275,11 +313,10 @@ int main(int argc, char** argv) {
                 cv_room.notify_one();
             }
             std::unique_ptr<Chunk> ch(new Chunk);
-            if (sl.view) {
-                parse_slice(sl.view, sl.view_len, hdr, L, ch.get());
-                // the slice's pages leave this process's resident set (they stay in the page cache)
-                const uintptr_t page = 4096, lo = ((uintptr_t)sl.view + page - 1) & ~(page - 1), hi = ((uintptr_t)sl.view + sl.view_len) & ~(page - 1);
-                if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
+            if (sl.from_file) {
+                if (text_buf.size() < sl.file_len) text_buf.resize(sl.file_len);
+                if (!pread_all(in_fd, text_buf.data(), sl.file_len, sl.file_off)) { fail("read error on the input file"); return; }
+                parse_slice(text_buf.data(), sl.file_len, hdr, L, ch.get());
             } else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
             std::string().swap(sl.text);
             if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
@@ -287,9 +324,26 @@ int main(int argc, char** argv) {
                 if (mgx_bgzf_store_put(store, ch->blob.data(), ch->blob.size(), &ch->dev_base)) { fail(std::string("GPU: ") + mgx_last_error()); return; }
                 std::vector<uint8_t>().swap(ch->blob);
             }
-            std::lock_guard<std::mutex> g(commit_mu);
-            ready.emplace(sl.seq, std::move(ch));
-            commit_ready();
+            {
+                // the writer's view of every record, in the slice's arrival order; the parse-time arrays die here
+                const size_t n = ch->recs.size();
+                ch->kept.resize(n);
+                for (size_t k = 0; k < n; ++k) {
+                    const uint32_t src = ch->input_index[k];
+                    const uint8_t* where = store ? (const uint8_t*)(uintptr_t)(ch->dev_base + ch->blob_off[src]) : ch->blob.data() + ch->blob_off[src];
+                    ch->kept[k] = Kept{where, (uint32_t)(ch->blob_off[src + 1] - ch->blob_off[src]), ch->tid[src], (int32_t)ch->pos[src], ch->end[src],
+                                       (ch->flag[src] & 4) == 0};
+                }
+                std::vector<uint32_t>().swap(ch->input_index);
+                std::vector<uint16_t>().swap(ch->flag); std::vector<int32_t>().swap(ch->tid); std::vector<int64_t>().swap(ch->pos);
+                std::vector<int32_t>().swap(ch->end); std::vector<uint64_t>().swap(ch->blob_off);
+            }
+            std::vector<std::vector<mgx_rec_t>> trash;
+            {
+                std::lock_guard<std::mutex> g(commit_mu);
+                ready.emplace(sl.seq, std::move(ch));
+                commit_ready(&trash);
+            }
         }
     };
     std::vector<std::thread> pool;
@@ -298,19 +352,37 @@ int main(int argc, char** argv) {
     // ---- reader: slices end where a queryname group ends
     uint64_t seq = 0;
     size_t window = slice_bytes;                             // grows only while one queryname group fills the whole window
+    std::vector<char> tail;
+    size_t tail_want = 64u << 10;                            // how much text before a tentative cut is inspected
     while (map && !failed.load() && map_pos < map_size) {
         const size_t limit = std::min(map_size - map_pos, window);
         size_t cut;
         if (limit == map_size - map_pos) cut = limit;
         else {
-            const char* last_nl = (const char*)memrchr(map + map_pos, '\n', limit);
-            cut = last_nl ? last_group_start(map + map_pos, (size_t)(last_nl - (map + map_pos)) + 1) : 0;
+            // the last complete line before map_pos + limit, and where its queryname group starts
+            const size_t tw = std::min(limit, tail_want);
+            const uint64_t a0 = map_pos + limit - tw;
+            tail.resize(tw);
+            if (!pread_all(in_fd, tail.data(), tw, a0)) { fail("read error on the input file"); break; }
+            const char* last_nl = (const char*)memrchr(tail.data(), '\n', tw);
+            size_t first = 0;                                // first byte of the first COMPLETE line in the tail
+            if (a0 > map_pos) { const char* nl0 = (const char*)memchr(tail.data(), '\n', tw); first = nl0 ? (size_t)(nl0 - tail.data()) + 1 : tw; }
+            size_t g = 0;
+            const bool have = last_nl && (size_t)(last_nl - tail.data()) + 1 > first;
+            if (have) g = first + last_group_start(tail.data() + first, (size_t)(last_nl - tail.data()) + 1 - first);
+            if (!have || g == first) {
+                // the group reaches the head of what was inspected: look further back, or (the whole window is one
+                // group) further ahead
+                if (a0 > map_pos) { tail_want *= 4; continue; }
+                if (!have || g == 0) { window *= 2; tail_want = 64u << 10; continue; }
+            }
+            cut = (size_t)(a0 - map_pos) + g;
             if (cut == 0) { window *= 2; continue; }
         }
-        window = slice_bytes;
+        window = slice_bytes; tail_want = 64u << 10;
         Slice sl;
         sl.seq = seq++;
-        sl.view = map + map_pos; sl.view_len = cut;
+        sl.from_file = true; sl.file_off = map_pos; sl.file_len = cut;
         map_pos += cut;
         std::unique_lock<std::mutex> lk(mu);
         cv_room.wait(lk, [&] { return queue.size() < queue_cap || failed.load(); });
@@ -349,8 +421,23 @@ int main(int argc, char** argv) {
     if (in_path) fclose(f);
     if (failed.load()) { fprintf(stderr, "%s\n", first_error.c_str()); return 1; }
     const size_t n = (size_t)n_total;
+    {
+        by_arrival.resize(n);
+        std::vector<std::thread> gang;
+        std::atomic<size_t> next_chunk{0};
+        for (int t = 0; t < std::max(1, std::min(threads, 16)); ++t)
+            gang.emplace_back([&]() {
+                for (size_t i; (i = next_chunk.fetch_add(1)) < kept_chunks.size();) {
+                    Chunk& ch = *kept_chunks[i];
+                    if (!ch.kept.empty()) memcpy(&by_arrival[ch.arrival_base], ch.kept.data(), ch.kept.size() * sizeof(Kept));
+                    std::vector<Kept>().swap(ch.kept);
+                }
+            });
+        for (auto& th : gang) th.join();
+    }
     printf("%zu alignment records, %zu reference sequences, %llu slices\n", n, hdr.ref_name.size(), (unsigned long long)seq);
     time_stamp("read + parse + pair + upload done");
+    if (getenv("MGX_CLI_TRACE")) fprintf(stderr, "  ingest: %.3f s inside the in-order commit (one thread at a time), %.3f s of it in mgx_sortdedup_upload_chunk\n", commit_seconds, upload_seconds);
 
     if (mgx_sortdedup_upload_end(sd, n)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
     std::vector<uint32_t> order(n); std::vector<uint8_t> dup(n);
