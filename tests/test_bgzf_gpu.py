@@ -181,3 +181,38 @@ def test_record_store_emits_the_sorted_marked_stream(comp, pkg, n, seed, len_ran
         blk = blocks[int(block_at[b]):int(block_at[b + 1])]
         d = zlib.decompressobj(-15)
         assert d.decompress(blk[18:-8]) + d.flush() == bytes(want[b * 0xff00:(b + 1) * 0xff00])
+
+
+def test_record_store_over_several_windows(comp, pkg):
+    """~260 MB of stream: four windows of 1024 blocks, three in flight -- the rotation of the batches and the records
+    that straddle two windows"""
+    rng = np.random.default_rng(21)
+    n = 700_000
+    lens = rng.integers(200, 520, n).astype(np.uint32)
+    off = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    data = np.tile(np.frombuffer(bam_like(rng, 4_000_000), dtype=np.uint8), int(off[-1]) // 4_000_000 + 1)[:int(off[-1])].copy()
+    data[off[:-1] + 15] &= 0xfb
+    store = pkg.BgzfStore(comp)
+    addr = np.zeros(n, dtype=np.uint64)
+    for a in range(0, n, 90_000):
+        b = min(n, a + 90_000)
+        addr[a:b] = store.put(data[off[a]:off[b]]) + (off[a:b] - off[a]).astype(np.uint64)
+    order = rng.permutation(n).astype(np.uint32)
+    dup = (rng.random(n) < 0.1).astype(np.uint8)
+    blocks, block_at, uoff = store.emit(order, dup, addr, lens)
+    store.close()
+    out_len = 4 + lens[order].astype(np.int64)
+    want_off = np.concatenate([[0], np.cumsum(out_len)])
+    assert np.array_equal(uoff.astype(np.int64), want_off)
+    got = np.frombuffer(gzip.decompress(blocks + pkg.bgzf.EOF_BLOCK), dtype=np.uint8)
+    assert len(got) == want_off[-1] and len(block_at) - 1 == (len(got) + 0xff00 - 1) // 0xff00 > 3 * 1024
+    # every record: length field, bytes, duplicate bit (checked in vectorised form on a sample of 60 000 and at the window seams)
+    win = 1024 * 0xff00
+    seams = np.unique(np.clip(np.searchsorted(want_off, np.arange(1, 4) * win)[:, None] + np.arange(-2, 3)[None, :], 0, n - 1).ravel())
+    for q in np.concatenate([rng.integers(0, n, 60_000), seams]):
+        r = int(order[q]); a = int(want_off[q]); L = int(lens[r])
+        assert int.from_bytes(got[a:a + 4].tobytes(), "little") == L
+        rec = data[off[r]:off[r] + L].copy()
+        if dup[r]:
+            rec[15] |= 4
+        assert np.array_equal(got[a + 4:a + 4 + L], rec), q

@@ -228,6 +228,21 @@ def test_cli_device_and_zlib_deflate_hold_the_same_stream(tmp_path, synth):
     assert sizes[0] < 1.25 * sizes[1] and sizes[2] < 1.25 * sizes[1]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("deflate", ["device", "pinned", "zlib"])
+def test_cli_header_only_input(tmp_path, deflate):
+    """no alignment records at all: a BAM with the header, the end-of-file block and an index without entries"""
+    sam, bam = str(tmp_path / "in.sam"), str(tmp_path / "out.bam")
+    header = "@HD\tVN:1.6\tSO:queryname\n@SQ\tSN:chr1\tLN:1000\n@SQ\tSN:chr2\tLN:500\n"
+    open(sam, "w").write(header)
+    res = subprocess.run([build_cli(), "-I", sam, "-O", bam, "-t", "2", "-z", deflate], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    text, refs, got = decode_bam(bam)
+    assert text == header and refs == [("chr1", 1000), ("chr2", 500)] and got == []
+    bai = open(bam + ".bai", "rb").read()
+    assert bai[:4] == b"BAI\x01" and struct.unpack_from("<i", bai, 4)[0] == 2
+
+
 def test_cli_usage_and_build(pkg):
     exe = build_cli()
     res = subprocess.run([exe], capture_output=True, text=True)
