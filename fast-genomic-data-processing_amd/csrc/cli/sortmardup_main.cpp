@@ -7,16 +7,20 @@
 //
 // Ingest is a pipeline over bounded slices of the text, the shape of the reference's reader thread feeding its
 // shuffle threads through a bounded queue of line blocks (main.cpp:505-562, 129-192):
-//   reader (main thread)   reads ~8 MB at a time, cuts at a template boundary (a queryname group never
-//                          straddles two slices, so mates are found inside their slice), queues the slice;
-//                          the queue is bounded, so at most 2 x threads slices of text are alive
-//   parsers (-t threads)   parse a slice into BAM-ready records and run mgx_sortdedup_pack on it (host keys,
-//                          arrival order, slice-local mate indices)
+//   reader (main thread)   cuts ~8 MB slices at a template boundary (a queryname group never straddles two slices,
+//                          so mates are found inside their slice) and queues them; of a regular file it only reads
+//                          the few KB around every cut, stdin it reads whole; the queue is bounded
+//   parsers (-t threads)   pread their slice (regular file), parse it into BAM-ready records, run
+//                          mgx_sortdedup_pack on it (host keys, arrival order, slice-local mate indices), hand the
+//                          BAM bytes to the device record store (-z device) and build the writer's per-record view
 //   commit (in slice order, by whichever parser finishes the next slice)
 //                          turns mate indices into global arrival indices and hands the packed records to
 //                          mgx_sortdedup_upload_chunk: staging and the PCIe copy run while later slices are
-//                          still being parsed; only the BAM bytes and 24 bytes of bookkeeping per record stay
-// then mgx_sortdedup_run (MI355X: radix sorts + duplicate search) and BGZF/BAM/BAI output (threads).
+//                          still being parsed
+// then mgx_sortdedup_run (MI355X: radix sorts + duplicate search) and the output: the records are gathered in sorted
+// order, duplicate-flagged and BGZF-compressed on the device (-z device, mgx_bgzf_store_emit), or gathered by writer
+// threads for the device compressor (-z pinned) or for zlib (-z zlib, the reference's way); BAI from the records'
+// virtual offsets.
 // There is no CPU fallback: without a HIP device the tool exits with an error.
 #include <fcntl.h>
 #include <getopt.h>
