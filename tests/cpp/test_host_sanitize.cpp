@@ -11,6 +11,7 @@
 #include "mgx_pairhmm.h"
 #include "mgx_sortdedup.h"
 #include "../../fast-genomic-data-processing_amd/csrc/pairhmm_pack.h"
+#include "../../fast-genomic-data-processing_amd/csrc/cli/sam_text.h"
 
 static uint64_t rng_state = 0x5EED;
 static uint64_t rnd() { rng_state += 0x9E3779B97F4A7C15ull; uint64_t z = rng_state; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
@@ -73,8 +74,51 @@ static int pack_case(uint64_t n_reads, uint64_t n_haps, uint64_t n_pairs, bool c
     return 0;
 }
 
+// The CLI's SAM text parser on well-formed, odd and broken lines (its integer parser and 4-bit sequence packing are
+// hand-written): every line either parses to the expected fields or is rejected with a message, nothing is read out of bounds.
+static int sam_case() {
+    samtext::Header h;
+    const std::string head = "@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:100000\n@SQ\tSN:chr2\tLN:5000\n";
+    if (samtext::parse_header(head.data(), head.size(), &h) != head.size() || h.ref_name.size() != 2 || h.ref_len[1] != 5000) return 10;
+    struct Case { const char* line; bool ok; int32_t pos; uint32_t l_seq; size_t n_cigar; size_t aux_bytes; };
+    const Case cases[] = {
+        {"r1\t99\tchr1\t1001\t60\t5M2I3M\t=\t1200\t300\tACGTNACGTA\tIIIIIIIIII\tNM:i:3\tRG:Z:g\tXA:A:c\tXF:f:1.5\tXB:B:s,-1,2,300", true, 1000, 10, 3, 4 + 5 + 4 + 7 + 14},        // NM:C, RG:Z, XA:A, XF:f, XB:B:s x 3
+        {"r2\t4\t*\t0\t0\t*\t*\t0\t0\tACG\t*", true, -1, 3, 0, 0},                    // odd length, no qualities, unmapped
+        {"r3\t16\tchr2\t+17\t0\t3S1M\tchr1\t-0\t-2147483647\tacgt\t!!!!\tXI:i:-40000\tXJ:i:4000000000", true, 16, 4, 2, 3 + 4 + 3 + 4},
+        {"r4\t0\tchr1\t1\t0\t*\t*\t0\t0\t*\t*", true, 0, 0, 0, 0},
+        {"r5\t0\tchr9\t1\t0\t*\t*\t0\t0\t*\t*", false, 0, 0, 0, 0},                      // unknown reference
+        {"r6\t0x10\tchr1\t1\t0\t*\t*\t0\t0\t*\t*", false, 0, 0, 0, 0},                   // FLAG is not decimal
+        {"r7\t0\tchr1\t99999999999999999999\t0\t*\t*\t0\t0\t*\t*", false, 0, 0, 0, 0},   // POS overflows
+        {"r8\t0\tchr1\t1\t0\t4M\t*\t0\t0\tACGT\tII", false, 0, 0, 0, 0},                 // SEQ and QUAL differ in length
+        {"r9\t0\tchr1\t1\t0\tM4\t*\t0\t0\t*\t*", false, 0, 0, 0, 0},                     // CIGAR without a count
+        {"r10\t0\tchr1\t1", false, 0, 0, 0, 0},                                              // fewer than 11 fields
+        {"r11\t0\tchr1\t1\t0\t*\t*\t0\t0\t*\t*\tNM:i:", false, 0, 0, 0, 0},             // empty integer tag
+        {"r12\t0\tchr1\t-\t0\t*\t*\t0\t0\t*\t*", false, 0, 0, 0, 0},                     // a sign alone
+    };
+    samtext::Record r; std::string err;
+    for (const Case& c : cases) {
+        const std::string line(c.line);                       // exact-size heap copy: an over-read is an ASan report
+        std::vector<char> exact(line.begin(), line.end());
+        err.clear();
+        const bool ok = samtext::parse_record(exact.data(), exact.size(), h, &r, &err);
+        if (ok != c.ok) { fprintf(stderr, "sam_case: '%s' parsed=%d (%s)\n", c.line, (int)ok, err.c_str()); return 11; }
+        if (!ok) { if (err.empty()) return 12; continue; }
+        if (r.pos != c.pos || r.l_seq != c.l_seq || r.cigar.size() != c.n_cigar || r.seq4.size() != (c.l_seq + 1) / 2 || r.qual.size() != c.l_seq) return 13;
+        if (c.aux_bytes && r.aux.size() != c.aux_bytes) { fprintf(stderr, "sam_case: aux of '%s' is %zu bytes\n", c.line, r.aux.size()); return 14; }
+    }
+    // r1's packed bases: A C G T N A C G T A -> 1 2 4 8 15 1 2 4 8 1
+    err.clear();
+    const std::string l1(cases[0].line);
+    if (!samtext::parse_record(l1.data(), l1.size(), h, &r, &err)) return 15;
+    const uint8_t want[5] = {0x12, 0x48, 0xF1, 0x24, 0x81};
+    if (memcmp(r.seq4.data(), want, 5) != 0 || r.qual[0] != 'I' - 33 || r.mtid != 0 || r.mpos != 1199 || r.tlen != 300) return 16;
+    const std::string l3(cases[2].line);
+    if (!samtext::parse_record(l3.data(), l3.size(), h, &r, &err) || r.tlen != -2147483647 || r.mpos != -1 || r.tid != 1 || r.mtid != 0) return 17;
+    return 0;
+}
+
 int main() {
-    int rc = 0;
+    int rc = sam_case();
     for (int it = 0; it < 40 && !rc; ++it) rc = route_case(1 + rnd() % 30000, 1 + (uint32_t)(rnd() % 9), 1000 + rnd() % 5000000);
     if (!rc) rc = route_case(400000, 8, 3100000000ull);         // large enough for the router's threads to split the work
     for (int it = 0; it < 20 && !rc; ++it) rc = pack_case(1 + rnd() % 200, 1 + rnd() % 50, rnd() % 3000, it % 3 == 0);

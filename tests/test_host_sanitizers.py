@@ -1,5 +1,5 @@
 """The host-only code of the library (record packing, the multi-GPU router / merge, the PairHMM batch packer and
-its callers' validation) under AddressSanitizer + UBSan and under ThreadSanitizer, CPU build, no device: the
+its callers' validation) and the CLI's SAM text parser under AddressSanitizer + UBSan and under ThreadSanitizer, CPU build, no device: the
 translation units are compiled directly with g++ (they contain no HIP) next to a small driver."""
 import os
 import subprocess
@@ -10,7 +10,7 @@ from conftest import ROOT
 
 PKGDIR = os.path.join(ROOT, "fast-genomic-data-processing_amd")
 SRC = [os.path.join(ROOT, "tests", "cpp", "test_host_sanitize.cpp"), os.path.join(PKGDIR, "csrc", "sortdedup_route.cpp"), os.path.join(PKGDIR, "csrc", "sortdedup_pack.cpp"), os.path.join(PKGDIR, "csrc", "pairhmm_pack_batch.cpp"),
-       os.path.join(PKGDIR, "csrc", "mgx_common.cpp")]
+       os.path.join(PKGDIR, "csrc", "mgx_common.cpp"), os.path.join(PKGDIR, "csrc", "cli", "sam_text.cpp")]
 
 
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])
