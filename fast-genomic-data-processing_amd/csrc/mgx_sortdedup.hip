@@ -434,6 +434,10 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sm) {
 // (8 wavefronts = 8192-key tiles double the run a digit leaves the tile with, but measured slower: see radix_sort.)
 // LOW32: last pass of the packed record sort -- only the low half of every key (the arrival index)
 // is stored, to pout32, which makes the sorted keys themselves unnecessary.
+#ifndef MGX_SORT_PREFETCH_P32
+#define MGX_SORT_PREFETCH_P32 1
+#endif
+constexpr bool kPrefetchP32 = MGX_SORT_PREFETCH_P32 != 0;     // the 32-bit payload is loaded with the keys, not between two barriers
 template <bool HAS_P64, bool HAS_P32, int WAVES, bool LOW32 = false>
 __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                               const u64* __restrict__ pin64, u64* __restrict__ pout64,
@@ -486,6 +490,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restr
         for (int k = 0; k < ITEMS; ++k) {
             const u32 li = wave * SLICE + k * 64 + lane;
             pay[k] = li < tile_n ? pin64[tile0 + li] : 0ull;
+        }
+    }
+    u32 pay32[(HAS_P32 && kPrefetchP32) ? ITEMS : 1];
+    if constexpr (HAS_P32 && kPrefetchP32) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const u32 li = wave * SLICE + k * 64 + lane;
+            pay32[k] = li < tile_n ? pin32[tile0 + li] : 0u;
         }
     }
 #pragma unroll
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restr
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             const u32 li = wave * SLICE + k * 64 + lane;
-            if (li < tile_n) sbuf32[lpos[k]] = pin32[tile0 + li];
+            if (li < tile_n) sbuf32[lpos[k]] = kPrefetchP32 ? pay32[kPrefetchP32 ? k : 0] : pin32[tile0 + li];
         }
         __syncthreads();
 #pragma unroll
