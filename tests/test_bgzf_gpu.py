@@ -216,3 +216,17 @@ def test_record_store_over_several_windows(comp, pkg):
         if dup[r]:
             rec[15] |= 4
         assert np.array_equal(got[a + 4:a + 4 + L], rec), q
+
+
+@pytest.mark.parametrize("env", [{"MGX_BGZF_GRID": "3"}, {"MGX_BGZF_LAZY": "0"}, {"MGX_BGZF_COST_BASE": "0"}, {"MGX_BGZF_COST_BASE": "30", "MGX_BGZF_COST_RLE": "30"}])
+def test_knobs_change_bytes_not_content(pkg, monkeypatch, env):
+    """three workgroups walking all blocks (LDS reused from block to block), no lazy evaluation, every match taken, almost
+    none taken: different compressed bytes, the same content"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = pkg.BgzfCompressor(0)
+    rng = np.random.default_rng(31)
+    data = bam_like(rng, 1_500_000) + rng.integers(0, 256, 70_000, dtype=np.uint8).tobytes() + bytes(100_000)
+    out, out_off = c.compress(data)
+    c.close()
+    assert gzip.decompress(bytes(out) + pkg.bgzf.EOF_BLOCK) == data
