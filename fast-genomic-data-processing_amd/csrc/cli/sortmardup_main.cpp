@@ -255,11 +255,27 @@ int main(int argc, char** argv) {
     uint64_t L = 0;
     for (uint64_t x : hdr.ref_len) L += x;
 
+    // The device contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start)
+    // while the first slices are already being parsed; a parser waits for them only when it has bytes for the device.
     mgx_bgzf_t* zctx = nullptr; mgx_bgzf_store_t* store = nullptr;
-    if (out_mode == kOutDevice && (mgx_bgzf_create(device, 0, &zctx) || mgx_bgzf_store_create(zctx, &store))) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
     mgx_sortdedup_t* sd = nullptr;
-    if (mgx_sortdedup_create(device, 0, &sd)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
-    if (mgx_sortdedup_upload_begin(sd, L, file_bytes / 256)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
+    const bool use_store = out_mode == kOutDevice;
+    std::mutex gpu_mu; std::condition_variable gpu_cv; int gpu_state = 0;          // 0 starting, 1 ready, -1 failed
+    std::string gpu_error;
+    std::thread gpu_init([&]() {
+        bool ok = true;
+        if (use_store && (mgx_bgzf_create(device, 0, &zctx) || mgx_bgzf_store_create(zctx, &store))) ok = false;
+        if (ok && (mgx_sortdedup_create(device, 0, &sd) || mgx_sortdedup_upload_begin(sd, L, file_bytes / 256))) ok = false;
+        std::lock_guard<std::mutex> g(gpu_mu);
+        if (!ok) gpu_error = mgx_last_error();
+        gpu_state = ok ? 1 : -1;
+        gpu_cv.notify_all();
+    });
+    auto gpu_ready = [&]() -> bool {
+        std::unique_lock<std::mutex> lk(gpu_mu);
+        gpu_cv.wait(lk, [&] { return gpu_state != 0; });
+        return gpu_state == 1;
+    };
 
     // ---- the pipeline
     std::mutex mu;
@@ -324,6 +340,7 @@ int main(int argc, char** argv) {
             } else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
             std::string().swap(sl.text);
             if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
+            if (!gpu_ready()) { fail("GPU: " + gpu_error); return; }
             if (store) {                                    // the slice's BAM bytes go to HBM now and leave host memory
                 if (mgx_bgzf_store_put(store, ch->blob.data(), ch->blob.size(), &ch->dev_base)) { fail(std::string("GPU: ") + mgx_last_error()); return; }
                 std::vector<uint8_t>().swap(ch->blob);
@@ -422,6 +439,8 @@ int main(int argc, char** argv) {
         cv_work.notify_all();
     }
     for (auto& th : pool) th.join();
+    gpu_init.join();
+    if (!gpu_ready()) { fprintf(stderr, "GPU: %s\n", gpu_error.c_str()); return 1; }
     if (in_path) fclose(f);
     if (failed.load()) { fprintf(stderr, "%s\n", first_error.c_str()); return 1; }
     const size_t n = (size_t)n_total;
