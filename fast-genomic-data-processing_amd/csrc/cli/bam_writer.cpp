@@ -294,34 +294,6 @@ const uint8_t kEofBlock[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B',
 
 }  // namespace
 
-int reg2bin(int64_t beg, int64_t end) {
-    --end;
-    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
-    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
-    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
-    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
-    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
-    return 0;
-}
-
-void encode_record(const samtext::Record& r, std::vector<uint8_t>* out) {
-    const size_t l_qn = r.qname.size() + 1, n_cig = r.cigar.size();
-    const size_t total = 32 + l_qn + 4 * n_cig + r.seq4.size() + r.qual.size() + r.aux.size();
-    const size_t at = out->size();
-    out->resize(at + total);
-    uint8_t* p = out->data() + at;
-    auto w = [&p](const void* src, size_t n) { memcpy(p, src, n); p += n; };
-    const int32_t tid = r.tid, pos = r.pos, l_seq = (int32_t)r.l_seq, mtid = r.mtid, mpos = r.mpos, tlen = r.tlen;
-    const uint16_t bin = (uint16_t)reg2bin(r.pos, r.end()), nc = (uint16_t)n_cig, flag = r.flag;
-    const uint8_t lq = (uint8_t)l_qn, mapq = r.mapq, zero = 0;
-    w(&tid, 4); w(&pos, 4); w(&lq, 1); w(&mapq, 1); w(&bin, 2); w(&nc, 2); w(&flag, 2); w(&l_seq, 4); w(&mtid, 4); w(&mpos, 4); w(&tlen, 4);
-    w(r.qname.data(), r.qname.size()); w(&zero, 1);
-    if (n_cig) w(r.cigar.data(), 4 * n_cig);
-    if (!r.seq4.empty()) w(r.seq4.data(), r.seq4.size());
-    if (!r.qual.empty()) w(r.qual.data(), r.qual.size());
-    if (!r.aux.empty()) w(r.aux.data(), r.aux.size());
-}
-
 bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
                int threads, int level, int device, std::string* err) {
     const bool trace = getenv("MGX_CLI_TRACE") != nullptr;

@@ -14,11 +14,7 @@
 
 namespace bamout {
 
-// BAM-encodes one record WITHOUT the leading block_size field (so the flag sits at byte 14).
-void encode_record(const samtext::Record& r, std::vector<uint8_t>* out);
-constexpr size_t kFlagOffset = 14;
-
-int reg2bin(int64_t beg, int64_t end);
+// (encode_record, kFlagOffset and reg2bin live next to the parser: sam_text.h)
 
 struct RecordRef {              // one record of the output, in output order
     const uint8_t* blob;        // encode_record() bytes

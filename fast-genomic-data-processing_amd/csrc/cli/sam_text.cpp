@@ -227,4 +227,125 @@ bool parse_record(const char* line, size_t len, const Header& h, Record* r, std:
     return true;
 }
 
+bool parse_record_into(const char* line, size_t len, const Header& h, Parsed* out, std::vector<uint32_t>* cigar, std::vector<uint8_t>* qual,
+                       std::vector<char>* qname, std::vector<uint8_t>* blob, std::string* err) {
+    const size_t cigar0 = cigar->size(), qual0 = qual->size(), qname0 = qname->size(), blob0 = blob->size();
+    auto bad = [&](const char* why) { cigar->resize(cigar0); qual->resize(qual0); qname->resize(qname0); blob->resize(blob0); *err = why; return false; };
+    const char* p = line; const char* end = line + len;
+    const char* f[11]; size_t n[11];
+    for (int k = 0; k < 11; ++k)
+        if (!next_field(p, end, &f[k], &n[k])) return bad("fewer than 11 fields");
+    int64_t v;
+    if (n[0] == 0 || n[0] > 254) return bad("bad QNAME length");
+    if (!to_int(f[1], n[1], &v) || v < 0 || v > 65535) return bad("bad FLAG");
+    const uint16_t flag = (uint16_t)v;
+    const bool no_ref = n[2] == 1 && f[2][0] == '*';
+    const int32_t tid = no_ref ? -1 : find_ref(h, f[2], n[2]);
+    if (tid < 0 && !no_ref) return bad("RNAME not in the header");
+    if (!to_int(f[3], n[3], &v)) return bad("bad POS");
+    const int32_t pos = (int32_t)v - 1;
+    if (!to_int(f[4], n[4], &v) || v < 0 || v > 255) return bad("bad MAPQ");
+    const uint8_t mapq = (uint8_t)v;
+    int64_t ref_len = 0;
+    if (!(n[5] == 1 && f[5][0] == '*')) {
+        uint64_t num = 0; bool have = false;
+        for (size_t i = 0; i < n[5]; ++i) {
+            const char ch = f[5][i];
+            if (ch >= '0' && ch <= '9') { num = num * 10 + (uint64_t)(ch - '0'); have = true; continue; }
+            int op;
+            switch (ch) {
+                case 'M': op = 0; break; case 'I': op = 1; break; case 'D': op = 2; break; case 'N': op = 3; break; case 'S': op = 4; break;
+                case 'H': op = 5; break; case 'P': op = 6; break; case '=': op = 7; break; case 'X': op = 8; break; case 'B': op = 9; break;
+                default: op = -1;
+            }
+            if (op < 0 || !have || num >= (1ull << 28)) return bad("bad CIGAR");
+            cigar->push_back((uint32_t)(num << 4) | (uint32_t)op);
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += (int64_t)num;
+            num = 0; have = false;
+        }
+        if (have) return bad("bad CIGAR");
+    }
+    const size_t n_cig = cigar->size() - cigar0;
+    const int32_t rec_end = (int32_t)(pos + (ref_len > 0 ? ref_len : 1));
+    int32_t mtid;
+    if (n[6] == 1 && f[6][0] == '=') mtid = tid;
+    else if (n[6] == 1 && f[6][0] == '*') mtid = -1;
+    else { mtid = find_ref(h, f[6], n[6]); if (mtid < 0) return bad("RNEXT not in the header"); }
+    if (!to_int(f[7], n[7], &v)) return bad("bad PNEXT");
+    const int32_t mpos = (int32_t)v - 1;
+    if (!to_int(f[8], n[8], &v)) return bad("bad TLEN");
+    const int32_t tlen = (int32_t)v;
+    const bool no_seq = n[9] == 1 && f[9][0] == '*';
+    const uint32_t l_seq = no_seq ? 0u : (uint32_t)n[9];
+    const bool no_qual = n[10] == 1 && f[10][0] == '*';
+    if (!no_qual && n[10] != l_seq) return bad("SEQ and QUAL differ in length");
+    // ---- the record's fixed part, name, CIGAR, bases, qualities: one resize, then plain stores
+    const size_t l_qn = n[0] + 1, n_seq4 = (l_seq + 1) / 2;
+    const size_t fixed = 32 + l_qn + 4 * n_cig + n_seq4 + l_seq;
+    blob->resize(blob0 + fixed);
+    uint8_t* w = blob->data() + blob0;
+    auto st = [&w](const void* src, size_t k) { if (k) memcpy(w, src, k); w += k; };
+    const int32_t l_seq_i = (int32_t)l_seq;
+    const uint16_t bin = (uint16_t)bamout::reg2bin(pos, rec_end), nc = (uint16_t)n_cig;
+    const uint8_t lq = (uint8_t)l_qn, zero = 0;
+    st(&tid, 4); st(&pos, 4); st(&lq, 1); st(&mapq, 1); st(&bin, 2); st(&nc, 2); st(&flag, 2); st(&l_seq_i, 4); st(&mtid, 4); st(&mpos, 4); st(&tlen, 4);
+    st(f[0], n[0]); st(&zero, 1);
+    if (n_cig) st(cigar->data() + cigar0, 4 * n_cig);
+    {
+        const uint8_t* nt16 = nt16_table();
+        const uint8_t* sq = (const uint8_t*)f[9];
+        size_t k = 0;
+        for (; 2 * k + 1 < l_seq; ++k) w[k] = (uint8_t)(nt16[sq[2 * k]] << 4 | nt16[sq[2 * k + 1]]);
+        if (l_seq & 1) w[k] = (uint8_t)(nt16[sq[l_seq - 1]] << 4);
+        w += n_seq4;
+    }
+    qual->resize(qual0 + l_seq);
+    uint8_t* q = qual->data() + qual0;
+    if (no_qual) { if (l_seq) memset(q, 0xFF, l_seq); }
+    else for (size_t i = 0; i < l_seq; ++i) q[i] = (uint8_t)(f[10][i] - 33);
+    st(q, l_seq);
+    qname->insert(qname->end(), f[0], f[0] + n[0]);
+    // ---- the optional fields straight onto the record
+    const char* af; size_t an;
+    while (p <= end && next_field(p, end, &af, &an)) {
+        if (an == 0) continue;
+        if (!parse_aux(af, an, *blob, err)) { const std::string why = *err; return bad(why.c_str()); }
+    }
+    out->flag = flag; out->tid = tid; out->pos = pos; out->end = rec_end;
+    return true;
+}
+
 }  // namespace samtext
+
+namespace bamout {
+
+int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+void encode_record(const samtext::Record& r, std::vector<uint8_t>* out) {
+    const size_t l_qn = r.qname.size() + 1, n_cig = r.cigar.size();
+    const size_t total = 32 + l_qn + 4 * n_cig + r.seq4.size() + r.qual.size() + r.aux.size();
+    const size_t at = out->size();
+    out->resize(at + total);
+    uint8_t* p = out->data() + at;
+    auto w = [&p](const void* src, size_t n) { memcpy(p, src, n); p += n; };
+    const int32_t tid = r.tid, pos = r.pos, l_seq = (int32_t)r.l_seq, mtid = r.mtid, mpos = r.mpos, tlen = r.tlen;
+    const uint16_t bin = (uint16_t)reg2bin(r.pos, r.end()), nc = (uint16_t)n_cig, flag = r.flag;
+    const uint8_t lq = (uint8_t)l_qn, mapq = r.mapq, zero = 0;
+    w(&tid, 4); w(&pos, 4); w(&lq, 1); w(&mapq, 1); w(&bin, 2); w(&nc, 2); w(&flag, 2); w(&l_seq, 4); w(&mtid, 4); w(&mpos, 4); w(&tlen, 4);
+    w(r.qname.data(), r.qname.size()); w(&zero, 1);
+    if (n_cig) w(r.cigar.data(), 4 * n_cig);
+    if (!r.seq4.empty()) w(r.seq4.data(), r.seq4.size());
+    if (!r.qual.empty()) w(r.qual.data(), r.qual.size());
+    if (!r.aux.empty()) w(r.aux.data(), r.aux.size());
+}
+
+
+}  // namespace bamout

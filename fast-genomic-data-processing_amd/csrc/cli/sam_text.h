@@ -39,4 +39,21 @@ size_t parse_header(const char* data, size_t size, Header* h);
 // Parses one alignment line [line, line + len) (no trailing newline).  Returns false and sets *err.
 bool parse_record(const char* line, size_t len, const Header& h, Record* out, std::string* err);
 
+// What the sort / mark-duplicate key derivation and the index need of one record, next to its BAM bytes.
+struct Parsed {
+    uint16_t flag; int32_t tid, pos, end;   // end: 0-based exclusive end on the reference (pos + 1 if no ref length)
+};
+// The same parse in one pass without a Record: the BAM encoding of the line (what bamout::encode_record makes of
+// parse_record's result, byte for byte) is APPENDED to *blob, its CIGAR operations / phred qualities / read name to
+// *cigar / *qual / *qname.  On failure nothing stays appended and *err says why.
+bool parse_record_into(const char* line, size_t len, const Header& h, Parsed* out, std::vector<uint32_t>* cigar, std::vector<uint8_t>* qual,
+                       std::vector<char>* qname, std::vector<uint8_t>* blob, std::string* err);
+
 }  // namespace samtext
+
+namespace bamout {
+// BAM-encodes one record WITHOUT the leading block_size field (so the flag sits at byte 14).
+void encode_record(const samtext::Record& r, std::vector<uint8_t>* out);
+constexpr size_t kFlagOffset = 14;
+int reg2bin(int64_t beg, int64_t end);
+}  // namespace bamout

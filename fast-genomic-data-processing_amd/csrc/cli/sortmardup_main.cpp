@@ -102,7 +102,6 @@ size_t last_group_start(const char* data, size_t size) {
 }
 
 void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64_t L_expected, Chunk* c) {
-    samtext::Record r;
     size_t off = 0, hi = size;
     {
         // sized from the text so that the vectors do not grow by doubling (a record is rarely under 100 bytes of text)
@@ -117,12 +116,13 @@ void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64
         const size_t next = off + len + 1;
         if (len && data[off + len - 1] == '\r') --len;
         if (len) {
-            if (!samtext::parse_record(data + off, len, h, &r, &c->err)) { c->err += " at: " + std::string(data + off, std::min<size_t>(len, 80)); return; }
-            c->flag.push_back(r.flag); c->tid.push_back(r.tid); c->pos.push_back(r.pos); c->end.push_back(r.end());
-            c->cigar.insert(c->cigar.end(), r.cigar.begin(), r.cigar.end()); c->cigar_off.push_back(c->cigar.size());
-            c->qual.insert(c->qual.end(), r.qual.begin(), r.qual.end()); c->qual_off.push_back(c->qual.size());
-            c->qname.insert(c->qname.end(), r.qname.begin(), r.qname.end()); c->qname_off.push_back(c->qname.size());
-            bamout::encode_record(r, &c->blob);
+            samtext::Parsed pr;
+            if (!samtext::parse_record_into(data + off, len, h, &pr, &c->cigar, &c->qual, &c->qname, &c->blob, &c->err)) {
+                c->err += " at: " + std::string(data + off, std::min<size_t>(len, 80));
+                return;
+            }
+            c->flag.push_back(pr.flag); c->tid.push_back(pr.tid); c->pos.push_back(pr.pos); c->end.push_back(pr.end);
+            c->cigar_off.push_back(c->cigar.size()); c->qual_off.push_back(c->qual.size()); c->qname_off.push_back(c->qname.size());
             c->blob_off.push_back(c->blob.size());
         }
         off = next;

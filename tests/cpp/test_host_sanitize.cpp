@@ -102,9 +102,47 @@ static int sam_case() {
         err.clear();
         const bool ok = samtext::parse_record(exact.data(), exact.size(), h, &r, &err);
         if (ok != c.ok) { fprintf(stderr, "sam_case: '%s' parsed=%d (%s)\n", c.line, (int)ok, err.c_str()); return 11; }
+        {
+            // the one-pass parser the CLI uses: the same verdict, and the bytes encode_record makes of the Record
+            std::vector<uint32_t> cg{7u}; std::vector<uint8_t> ql{9}; std::vector<char> qn{'x'}; std::vector<uint8_t> blob{1, 2, 3}, want{1, 2, 3};
+            samtext::Parsed pr{}; std::string err2;
+            const bool ok2 = samtext::parse_record_into(exact.data(), exact.size(), h, &pr, &cg, &ql, &qn, &blob, &err2);
+            if (ok2 != ok) { fprintf(stderr, "sam_case: one-pass parser disagrees on '%s' (%s)\n", c.line, err2.c_str()); return 18; }
+            if (!ok2) { if (cg.size() != 1 || ql.size() != 1 || qn.size() != 1 || blob.size() != 3 || err2.empty()) return 19; }
+            else {
+                bamout::encode_record(r, &want);
+                if (blob != want || pr.flag != r.flag || pr.tid != r.tid || pr.pos != r.pos || pr.end != r.end()) { fprintf(stderr, "sam_case: one-pass bytes differ on '%s'\n", c.line); return 20; }
+                if (cg.size() != 1 + r.cigar.size() || memcmp(cg.data() + 1, r.cigar.data(), 4 * r.cigar.size()) != 0) return 21;
+                if (ql.size() != 1 + r.qual.size() || memcmp(ql.data() + 1, r.qual.data(), r.qual.size()) != 0) return 22;
+                if (qn.size() != 1 + r.qname.size() || memcmp(qn.data() + 1, r.qname.data(), r.qname.size()) != 0) return 23;
+            }
+        }
         if (!ok) { if (err.empty()) return 12; continue; }
         if (r.pos != c.pos || r.l_seq != c.l_seq || r.cigar.size() != c.n_cigar || r.seq4.size() != (c.l_seq + 1) / 2 || r.qual.size() != c.l_seq) return 13;
         if (c.aux_bytes && r.aux.size() != c.aux_bytes) { fprintf(stderr, "sam_case: aux of '%s' is %zu bytes\n", c.line, r.aux.size()); return 14; }
+    }
+    // mutated copies of the valid lines (a byte replaced, dropped or doubled): the two parsers agree on the verdict and the bytes
+    for (int it = 0; it < 20000; ++it) {
+        std::string line(cases[rnd() % 4].line);
+        for (int m = 0, nm = 1 + (int)(rnd() % 3); m < nm && !line.empty(); ++m) {
+            const size_t at = rnd() % line.size();
+            const char repl[] = "\t*:=0123456789-+ACGTNMIDSHXBZifsc,.!~";
+            switch (rnd() % 3) {
+                case 0: line[at] = repl[rnd() % (sizeof repl - 1)]; break;
+                case 1: line.erase(at, 1); break;
+                default: line.insert(at, 1, line[at]); break;
+            }
+        }
+        std::vector<char> exact(line.begin(), line.end());
+        std::string e1, e2;
+        samtext::Record r1;
+        std::vector<uint32_t> cg; std::vector<uint8_t> ql; std::vector<char> qn; std::vector<uint8_t> blob, want;
+        samtext::Parsed pr{};
+        const bool o1 = samtext::parse_record(exact.data(), exact.size(), h, &r1, &e1);
+        const bool o2 = samtext::parse_record_into(exact.data(), exact.size(), h, &pr, &cg, &ql, &qn, &blob, &e2);
+        if (o1 != o2) { fprintf(stderr, "sam_case: parsers disagree on '%s' (%s | %s)\n", line.c_str(), e1.c_str(), e2.c_str()); return 24; }
+        if (o1) { bamout::encode_record(r1, &want); if (blob != want) { fprintf(stderr, "sam_case: bytes differ on '%s'\n", line.c_str()); return 25; } }
+        else if (!blob.empty() || !cg.empty() || !ql.empty() || !qn.empty()) return 26;
     }
     // r1's packed bases: A C G T N A C G T A -> 1 2 4 8 15 1 2 4 8 1
     err.clear();
