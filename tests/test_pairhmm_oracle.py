@@ -100,6 +100,8 @@ def test_no_cpu_fallback(pkg):
         pytest.skip("GPU present")
     with pytest.raises(pkg.MgxError, match="no HIP device"):
         pkg.PairHMMEngine(0)
+    with pytest.raises(pkg.MgxError, match="no HIP device"):
+        pkg.BgzfCompressor(0)
 
 
 def test_product_does_not_reference_oracle():
