@@ -1132,6 +1132,9 @@ int mgx_bgzf_store_emit(mgx_bgzf_store_t* st, uint64_t n, const uint32_t* order,
     if (!st || !sink || !uoff_out || (n && (!order || !dup || !addr || !len))) { set_error("NULL argument"); return -EINVAL; }
     mgx_bgzf* c = st->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    const bool trace = getenv("MGX_BGZF_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
     uoff_out[0] = 0;
     if (n == 0) return 0;
     if (n > 0xFFFFFFF0ull) { set_error("more than 2^32 records"); return -E2BIG; }
@@ -1163,9 +1166,6 @@ int mgx_bgzf_store_emit(mgx_bgzf_store_t* st, uint64_t n, const uint32_t* order,
     STORE_TRY(hipMemcpyAsync(uoff_out, d_uoff, (n + 1) * sizeof(u64), hipMemcpyDeviceToHost, s));
     STORE_TRY(hipStreamSynchronize(s));
     const u64 total = uoff_out[n];
-    const bool trace = getenv("MGX_BGZF_TRACE") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
     double t_wait = 0, t_sink = 0;
     if (trace) fprintf(stderr, "  store_emit: arrays on the device, offsets scanned and back: %.3f s\n", now());
     constexpr u32 kPer = 1024;                                    // blocks per batch (67 MB of the stream)
