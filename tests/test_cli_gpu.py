@@ -184,6 +184,21 @@ def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads, slice_
     blocks = bgzf_blocks(bam)
     c2u = {c: u for c, u, _ in blocks}
     data = gzip.decompress(open(bam, "rb").read())
+    # where every record starts in the uncompressed stream, with its reference span (from the decoded records)
+    rec_starts = {}
+    q0 = data.index(b"BAM\x01")
+    l_text, = struct.unpack_from("<i", data, 4)
+    q0 = 8 + l_text
+    n_r, = struct.unpack_from("<i", data, q0); q0 += 4
+    for _ in range(n_r):
+        l_nm, = struct.unpack_from("<i", data, q0); q0 += 4 + l_nm + 4
+    while q0 < len(data):
+        bs, tid, pos, l_qn, mapq, bn, n_cig = struct.unpack_from("<iiiBBHH", data, q0)
+        cig = struct.unpack_from(f"<{n_cig}I", data, q0 + 36 + l_qn)
+        ref_len = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+        if tid >= 0:
+            rec_starts.setdefault(tid, []).append((q0, (pos, pos + (ref_len if ref_len > 0 else 1))))
+        q0 += 4 + bs
     p = 8
     indexed = 0
     for ref in range(n_ref):
@@ -202,7 +217,23 @@ def test_cli_end_to_end(tmp_path, synth, sd_oracle, n_templates, threads, slice_
                     indexed += 1
                     q += 4 + bs
                 assert q == ue
-        n_intv, = struct.unpack_from("<i", bai, p); p += 4 + 8 * n_intv
+        n_intv, = struct.unpack_from("<i", bai, p); p += 4
+        linear = struct.unpack_from(f"<{n_intv}Q", bai, p); p += 8 * n_intv
+        # linear index: window w (16 kbp) holds the smallest virtual offset of a record of this reference that overlaps it
+        # (an empty window repeats the previous one), and that offset points at such a record's start
+        want = {}
+        for off_u, r in rec_starts.get(ref, []):
+            for w in range(max(r[0], 0) >> 14, ((max(r[1], r[0] + 1) - 1) >> 14) + 1):
+                want.setdefault(w, off_u)                      # the stream is coordinate-sorted: the first one seen is the smallest
+        assert n_intv == (max(want) + 1 if want else 0)
+        last = 0
+        for w in range(n_intv):
+            v = linear[w]
+            if w in want:
+                assert c2u[v >> 16] + (v & 0xffff) == want[w], (ref, w)
+                last = v
+            else:
+                assert v == last, (ref, w)
     n_no_coor, = struct.unpack_from("<Q", bai, p)
     assert n_no_coor == sum(1 for r in recs if r["tid"] < 0)
     assert indexed == sum(1 for r in recs if r["tid"] >= 0)
