@@ -500,6 +500,7 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             __syncthreads();                                // the scan's partial sums are about to be reused by the CRC
         }
 #undef MGX_LEN_AT
+        lap(13);
         // ---- 5. CRC-32 of the chunk, shifted to the end of the block
         {
             u32 c = tid == 0 ? 0xFFFFFFFFu : 0u;
@@ -909,6 +910,7 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
         if (hipMemcpy(p, c->d_prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess && c->n_blocks) {
             fprintf(stderr, "mgx_bgzf cycles per block: load %llu, match %llu, parse+crc %llu, tokens %llu, huffman %llu, header %llu, emit %llu\n", p[0] / c->n_blocks,
                     p[1] / c->n_blocks, p[2] / c->n_blocks, p[3] / c->n_blocks, p[4] / c->n_blocks, p[5] / c->n_blocks, p[6] / c->n_blocks);
+            fprintf(stderr, "   parse alone (the rest of parse+crc is the CRC): %llu\n", p[13] / c->n_blocks);
             fprintf(stderr, "   literal/length code: setup %llu, rank %llu, merge rounds %llu, depths %llu, codes %llu\n", p[8] / c->n_blocks, p[9] / c->n_blocks, p[10] / c->n_blocks, p[11] / c->n_blocks, p[12] / c->n_blocks);
         }
         (void)hipFree(c->d_prof);
