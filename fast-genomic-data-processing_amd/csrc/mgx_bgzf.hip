@@ -67,13 +67,15 @@ constexpr int kNumLL = 286, kNumD = 30, kNumCL = 19;
 constexpr int kAhead = 4;                      // windows whose tokens are fetched ahead of their use (one memory round trip per 16)
 constexpr u32 kScratchPerWg = 2u * (65536u + kAhead * 1024u);     // the match table by position, then the tokens, densely     // u32 per workgroup: decided matches, then packed tokens, by position
 
-enum { V_OVER = 0, V_NUSED, V_K, V_NTOK, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
+enum { V_OVER = 0, V_NUSED, V_K, V_CRCLAST, V_NTOK, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
 
 struct __attribute__((aligned(16))) Lds {
     u32 buf[(0x10000 + 512) / 4];              // the block's bytes (at the source's alignment), later the output words
     u32 head[1 << kHashBits];                  // hash -> last position + 1
     u32 crc_tab[4][256];                       // slicing-by-4 tables
     u32 x2n[32];                               // x^(2^k) mod P
+    u32 tpow[kNT];                             // x^(512 j) mod P
+    u32 xr[65];                                // x^(8 r) mod P
     u32 f_ll[288], f_d[32], f_cl[20];          // symbol counts
     u16 c_ll[288], c_d[32], c_cl[20];          // codes, bit-reversed for LSB-first output
     u8 l_ll[288], l_d[32], l_cl[20];           // code lengths
@@ -346,6 +348,20 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         for (int k = 1; k < 32; ++k) { p = multmodp(p, p); L.x2n[k] = p; }
     }
     __syncthreads();
+    {
+        // x^(512 j) for j < 1024 (what shifts a chunk's CRC over j later chunks of 64 bytes) and x^(8 r) for r <= 64 (over
+        // the last, shorter chunk): products of the x^(2^k) above, made once per workgroup
+        u32 tp = 0x80000000u;
+        for (int k = 0; k < 10; ++k) if ((tid >> k) & 1u) tp = multmodp(L.x2n[9 + k], tp);
+        L.tpow[tid] = tp;
+        if (tid <= 64) {
+            u32 xr = 0x80000000u;
+            const u32 e = 8u * tid;
+            for (int k = 0; k < 10; ++k) if ((e >> k) & 1u) xr = multmodp(L.x2n[k], xr);
+            L.xr[tid] = xr;
+        }
+    }
+    __syncthreads();
 
     for (u32 blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
         const u64 o0 = a.off[blk];
@@ -510,10 +526,12 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
                 c = L.crc_tab[3][x & 0xffu] ^ L.crc_tab[2][(x >> 8) & 0xffu] ^ L.crc_tab[1][(x >> 16) & 0xffu] ^ L.crc_tab[0][x >> 24];
             }
             for (; p < lo + cl; ++p) c = L.crc_tab[0][(c ^ in[p]) & 0xffu] ^ (c >> 8);
-            u32 e = 8u * (n - (lo + cl)), xp = 0x80000000u;
-            if (lo >= n) e = 0;
-            for (int k = 0; e; ++k, e >>= 1) if (e & 1u) xp = multmodp(L.x2n[k], xp);
-            const u32 part = wave_last(wave_scan_inclusive(multmodp(xp, c), OpXor()));
+            // chunks 0 .. nc-2 are followed by r + 64 (nc - 2 - t) bytes (r = size of the last chunk): one multiplication
+            // by the table's power here, the common factor x^(8 r) once after the reduction; the last chunk's state as it is
+            const u32 nc = (n + 63u) >> 6;
+            const u32 shifted = tid + 2u <= nc ? multmodp(L.tpow[nc - 2u - tid], c) : 0u;
+            if (tid + 1u == (nc ? nc : 1u)) L.vars[V_CRCLAST] = c;
+            const u32 part = wave_last(wave_scan_inclusive(shifted, OpXor()));
             if ((tid & 63u) == 0) L.wsum[tid >> 6] = part;
         }
         if (tid == 0) L.f_ll[256] = 1;             // end of block
@@ -521,7 +539,9 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         if (tid == 0) {
             u32 c = 0;
             for (int i = 0; i < kNT / 64; ++i) c ^= L.wsum[i];
-            L.vars[V_CRC] = c ^ 0xFFFFFFFFu;
+            const u32 nc = (n + 63u) >> 6;
+            const u32 r = nc ? n - 64u * (nc - 1u) : 0u;
+            L.vars[V_CRC] = multmodp(L.xr[r], c) ^ L.vars[V_CRCLAST] ^ 0xFFFFFFFFu;
         }
         lap(2);
         // ---- tokens, position-parallel: the token starting at a position in packed form, stored densely, and the symbol counts
