@@ -195,24 +195,33 @@ __device__ __forceinline__ u32 block_scan(Lds& L, u32 v, u32* total) {
 // At least two symbols get a code (inflate accepts no incomplete literal/length or code-length code).
 // Parallel but for the merge itself: ranks by counting, leaf depths by walking up the parent links, code values by
 // counting the earlier symbols of the same length.
+// WAVE (N <= 64: the distance and the code-length alphabets): wavefront 0 does it alone -- the LDS executes a wavefront's
+// instructions in order, so its lanes need no workgroup barrier between the steps -- and the others wait at the exit.
+template <bool WAVE>
 __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int limit, u8* len, u16* code, unsigned long long* prof = nullptr) {
     const int tid = (int)threadIdx.x;
     long long tp = prof ? clock64() : 0;
     auto lap = [&](int k) { if (prof && tid == 0) { const long long t = clock64(); atomicAdd(&prof[k], (unsigned long long)(t - tp)); tp = t; } };
+    auto sync = [] {
+        if constexpr (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
     __syncthreads();
+    if (WAVE && tid >= 64) { __syncthreads(); return; }
     if (tid < N) L.fw[tid] = freq_in[tid];            // the caller's counts stay as they are (they price the block)
     u32* const freq = L.fw;
-    const int used = __syncthreads_count(tid < N && freq[tid] != 0);
+    sync();
+    const int used = WAVE ? (int)__popcll(__ballot(tid < N && freq[tid] != 0)) : __syncthreads_count(tid < N && freq[tid] != 0);
     if (tid == 0) {
         if (used == 0) { freq[0] = 1; freq[1] = 1; }
         else if (used == 1) freq[freq[0] ? 1 : 0] = 1;
     }
     lap(8);
     for (;;) {
-        __syncthreads();
+        sync();
         if (tid < 16) L.bl_count[tid] = 0;
         if (tid == 0) { L.vars[V_NUSED] = 0; L.vars[V_OVER] = 0; }
-        __syncthreads();
+        sync();
         if (tid < N) {
             len[tid] = 0;
             const u32 f = freq[tid];
@@ -224,7 +233,7 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
                 atomicAdd(&L.vars[V_NUSED], 1u);
             }
         }
-        __syncthreads();
+        sync();
         lap(9);
         const int n = (int)L.vars[V_NUSED];
         {
@@ -239,14 +248,14 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
             u16* qi[2] = {L.qid[0], L.qid[1]};
             if (tid < n) L.qid[0][tid] = (u16)tid;                       // leaves 0 .. n-1 in weight order (rank step above)
             if (tid == 0) L.vars[V_K] = (u32)n;
-            __syncthreads();
+            sync();
             u32 m = (u32)n, next_id = (u32)n;
             int cur = 0;
             while (m > 1) {
                 const u32* w = qw[cur];
                 const u32 t = w[0] + w[1];
                 if ((u32)tid + 1 < m && w[tid] <= t && w[tid + 1] > t) L.vars[V_K] = (u32)tid + 1;     // at most one thread: Q is sorted
-                __syncthreads();
+                sync();
                 const u32 k = L.vars[V_K] & ~1u, a = m - k, b = k >> 1;
                 if ((u32)tid < b) {                                      // new node tid of this round
                     const u32 nw = w[2 * tid] + w[2 * tid + 1];
@@ -262,12 +271,12 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
                     qw[cur ^ 1][((u32)tid - k) + lo] = ow; qi[cur ^ 1][((u32)tid - k) + lo] = qi[cur][tid];
                 }
                 m = a + b; next_id += b; cur ^= 1;
-                __syncthreads();
+                sync();
                 if (tid == 0) L.vars[V_K] = m;                           // the next round's default: everything is <= t
-                __syncthreads();
+                sync();
             }
         }
-        __syncthreads();
+        sync();
         lap(10);
         if (tid < n) {                               // depth of leaf tid: steps to the root (node 2n - 2)
             int d = 0;
@@ -276,7 +285,7 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
             len[L.sorted[tid]] = (u8)d;
             atomicAdd(&L.bl_count[d < 16 ? d : 15], 1u);
         }
-        __syncthreads();
+        sync();
         lap(11);
         if (!L.vars[V_OVER]) break;
         if (tid < N) { const u32 f = freq[tid]; if (f) freq[tid] = (f + 1) >> 1; }     // flatter, still >= 1
@@ -287,7 +296,7 @@ __device__ void huff_build(Lds& L, const u32* freq_in, const int N, const int li
         L.bl_count[0] = 0;
         for (int bits = 1; bits <= 15; ++bits) { c = (c + L.bl_count[bits - 1]) << 1; L.next_code[bits] = c; }
     }
-    __syncthreads();
+    sync();
     if (tid < N) {
         const u32 l = len[tid];
         u32 c = 0;
@@ -578,8 +587,8 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         lap(3);
 
         // ---- 3. codes
-        huff_build(L, L.f_ll, kNumLL, 15, L.l_ll, L.c_ll, a.prof);
-        huff_build(L, L.f_d, kNumD, 15, L.l_d, L.c_d);
+        huff_build<false>(L, L.f_ll, kNumLL, 15, L.l_ll, L.c_ll, a.prof);
+        huff_build<true>(L, L.f_d, kNumD, 15, L.l_d, L.c_d);
         lap(4);
         // the header (RFC 1951 3.2.7), in parallel: the nlit + ndist code lengths are cut into runs (ballots), every run
         // knows how many code-length symbols it becomes (16: repeat 3-6, 17 / 18: zeros 3-10 / 11-138), a scan places them
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             }
             if (tid == 0) L.vars[V_NCLSYM] = ns;
         }
-        huff_build(L, L.f_cl, kNumCL, 7, L.l_cl, L.c_cl);
+        huff_build<true>(L, L.f_cl, kNumCL, 7, L.l_cl, L.c_cl);
         if (tid == 0) {
             const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             u32 word = 0, nbits = 0; u64 acc = 0;
