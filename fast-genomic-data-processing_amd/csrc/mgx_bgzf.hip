@@ -441,6 +441,11 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             if (base >= n) break;
             const u32 p = base + tid;
             u32 len = 0, dist = 0;
+            // runs: byte p equals byte p - 1.  The wavefront's 64 flags in one ballot give every lane the length of the
+            // distance-1 match at its position (its run of set flags) without a compare loop; only a run that reaches the
+            // end of the wavefront's 64 positions is followed further
+            const bool run_flag = p >= 1 && p < n && in[p - 1] == in[p];
+            const u64 run_mask = __ballot(run_flag);
             if (p < n) {
                 const u32 maxlen = min(258u, n - p);
                 const u32 cand = L.cand[grp & 1][g * kWin + tid];
@@ -451,8 +456,12 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
                         if (l >= 4) { len = l; dist = d; }
                     }
                 }
-                if (p >= 1 && maxlen >= 3 && in[p - 1] == in[p]) {
-                    const u32 l = match_len(in + p - 1, in + p, maxlen);
+                if (run_flag && maxlen >= 3) {
+                    const u32 ln = tid & 63u;
+                    const u64 rest = ~(run_mask >> ln);
+                    u32 l = rest ? (u32)__builtin_ctzll(rest) : 64u;              // <= 64 - ln
+                    if (ln + l == 64u && l < maxlen) l += match_len(in + p - 1 + l, in + p + l, maxlen - l);
+                    l = min(l, maxlen);
                     if (l >= 3 && l >= len) { len = l; dist = 1; }
                 }
                 if (len && len <= 16 && a.cost_base) {
