@@ -446,16 +446,29 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             // end of the wavefront's 64 positions is followed further
             const bool run_flag = p >= 1 && p < n && in[p - 1] == in[p];
             const u64 run_mask = __ballot(run_flag);
+            // Hash candidates: inside a repeated stretch neighbouring positions point the same distance back, and then the
+            // match at p + 1 is the match at p less its first byte.  Only the first lane of such a stretch (and lanes beyond
+            // the end of their head's match) extend their candidate; the others take the head's length minus their offset.
+            const u32 lane_ = tid & 63u;
+            const u32 maxlen_ = p < n ? min(258u, n - p) : 0u;
+            u32 cdist = 0;
+            if (p < n) { const u32 cand = L.cand[grp & 1][g * kWin + tid]; if (cand && p - (cand - 1) <= 32768u) cdist = p - (cand - 1); }
+            const u32 prev_dist = (u32)__builtin_amdgcn_update_dpp(0, (int)cdist, 0x138, 0xf, 0xf, false);      // wave_shr:1: lane i reads lane i - 1
+            const bool head = cdist != 0 && (lane_ == 0 || cdist != prev_dist);
+            u32 hlen = 0;
+            if (head) hlen = match_len(in + p - cdist, in + p, maxlen_);
+            const u64 head_mask = __ballot(head);
+            const u64 below = head_mask & (lane_ == 63u ? ~0ull : ((2ull << lane_) - 1ull));
+            const u32 head_lane = below ? 63u - (u32)__builtin_clzll(below) : 0u;
+            const u32 head_len = (u32)__shfl((int)hlen, (int)head_lane, 64);
+            u32 clen = hlen;
+            if (cdist != 0 && !head) {
+                const u32 off = lane_ - head_lane;
+                clen = head_len > off ? head_len - off : match_len(in + p - cdist, in + p, maxlen_);     // past the head's match: on its own
+            }
             if (p < n) {
-                const u32 maxlen = min(258u, n - p);
-                const u32 cand = L.cand[grp & 1][g * kWin + tid];
-                if (cand) {
-                    const u32 q = cand - 1, d = p - q;
-                    if (d <= 32768u) {
-                        const u32 l = match_len(in + q, in + p, maxlen);
-                        if (l >= 4) { len = l; dist = d; }
-                    }
-                }
+                const u32 maxlen = maxlen_;
+                if (clen >= 4) { len = clen; dist = cdist; }
                 if (run_flag && maxlen >= 3) {
                     const u32 ln = tid & 63u;
                     const u64 rest = ~(run_mask >> ln);
