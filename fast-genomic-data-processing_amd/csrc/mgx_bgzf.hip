@@ -55,7 +55,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 constexpr u32 kWin = 960;                       // positions per match window: 15 wavefronts extend matches, the 16th feeds them
-constexpr u32 kGrp = 4;                         // match windows between two workgroup barriers
+constexpr u32 kGrp = 8;                         // match windows between two workgroup barriers
 constexpr int kNT = 1024;                      // threads per workgroup = positions per match window (16 wavefronts: one block per CU, LDS-bound)
 constexpr int kHashBits = 12;
 constexpr u32 kMaxIn = MGX_BGZF_MAX_BLOCK_IN;
