@@ -90,6 +90,35 @@ def cpu_baseline(synth, n_sample, seed):
                       f"{d['cells'] / 1e9:.2f} Gcells in {dt:.2f} s wall on {cores} threads"}
 
 
+def sort_cpu_baseline(pkg, L, recs):
+    """The CPU checker (oracle/sortdedup_oracle.c, a qsort-based restatement; the reference's TBB main.cpp is unlinkable,
+    DESIGN.md 2) on ALL host cores, the way the reference uses them: the sample is range-partitioned by key
+    (sortmardup/tbb/range_partitioner.h:98-100; here the product's host router, one coordinate range per core) and the
+    partitions are sorted and searched for duplicates in parallel (sortmardup/main.cpp:249-357, tbb::parallel_for over
+    partitions).  Timed: the parallel per-partition work; the partitioning itself is reported beside it."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import SortDedupOracle
+    cores = host_cores()
+    ns = min(len(recs), 32_000_000)
+    ns -= ns % 2
+    orc = SortDedupOracle()
+    t0 = time.perf_counter()
+    routed = pkg.Routed(L, recs[:ns], cores)
+    shards = [routed.shard_arrays(k) for k in range(cores)]
+    route_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    bitmap = np.zeros((4 * L >> 6) + 2, dtype=np.uint64)      # the reference's ONE 4L-bit indicator (main.cpp:115), pages touched on demand
+    with ThreadPoolExecutor(cores) as ex:                     # ctypes releases the GIL around the C call
+        res = list(ex.map(lambda sh: orc.run_shard(L, sh, bitmap), shards))
+    cdt = time.perf_counter() - t0
+    routed.close()
+    return {"value": ns / cdt / 1e6, "unit": "Mrecords/s", "cores": cores, "kind": "port",
+            "sample": f"first {ns} records of the set, range-partitioned into {cores} coordinate shards ({route_s:.2f} s, not timed) and "
+                      f"sorted + searched for duplicates on {cores} threads by the qsort-based restatement, {cdt:.2f} s wall",
+            "records_ordered": int(sum(len(o) for o, _ in res))}
+
+
 def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backend="nccl"):
     """GPU radix sorts + duplicate marking of BASELINE.json configs[3], records resident in HBM.  N = 1: the whole
     200 M-record set on one GPU.  N > 1: the SAME set (every rank generates it from the same seed) routed into N
@@ -182,16 +211,7 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backe
                                   "unit": "GB/s", "frac": st["alg_bytes"] / (st["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "note": "LSD-8 traffic model of SURVEY.md 8d (307.5 B/record at this config) over the whole pipeline"}}
         if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from conftest import SortDedupOracle
-            ns = min(n, 4_000_000)
-            orc = SortDedupOracle()
-            t0 = time.perf_counter()
-            orc.run(L, recs[:ns] if ns % 2 == 0 else recs[:ns - 1])
-            cdt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": ns / cdt / 1e6, "unit": "Mrecords/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ns} records of the shard (mates kept together), "
-                                             f"serial qsort-based restatement, {cdt:.2f} s"}
+            out["cpu_baseline"] = sort_cpu_baseline(pkg, L, recs)
     eng.close()
     return out
 
@@ -380,17 +400,25 @@ def timed_resident(eng, batch, steps, warmup, barrier):
 
 
 def pairhmm_rooflines(st, traffic):
+    """the binding roof of the PairHMM recurrence is fp32 VECTOR issue (12 flop per cell against the
+    157.3 TFLOP/s vector peak), so that is what `roofline` reports; the HBM fraction BASELINE.json's
+    metric asks for -- 5R+H+4 algorithmic bytes per test case against 8 TB/s -- rides beside it as `roofline.hbm`."""
     ms_dom = st["ms_f32_dominant"]
     alg_bytes = st["dominant_alg_bytes"]
     achieved = alg_bytes / (ms_dom * 1e-3) / 1e9
     valu = 12.0 * st["dominant_cells"] / (ms_dom * 1e-3) / 1e12
-    return ({"bound": "hbm", "limiter": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-             "traffic": traffic, "traffic_source": "offline rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in this run" if traffic else None,
-             "kernel": st["dominant_kernel"], "kernel_ms": ms_dom, "kernel_ms_source": f"HIP events on the compute stream around every launch inside the timed loop, mean of {st['n_runs_timed']} runs",
-             "step_kernels_ms": st["ms_f32"] + st["ms_f64"], "alg_bytes_per_launch": alg_bytes,
-             "note": "5R+H+4 algorithmic bytes per test case (SURVEY.md 8d); the kernel is fp32-VALU-issue bound, not HBM bound -- see valu"},
-            {"achieved": valu, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu / VALU_FP32_PEAK_TFLOPS,
-             "kernel_gcups": st["dominant_cells"] / (ms_dom * 1e-3) / 1e9, "note": "12 flop per cell (SURVEY.md 8d) against the fp32 vector peak"})
+    hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": alg_bytes,
+           "note": "5R+H+4 algorithmic bytes per test case (SURVEY.md 8d); at 36 cells per byte no correct PairHMM kernel comes near this roof"}
+    roof = {"bound": "valu", "achieved": valu, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu / VALU_FP32_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": "offline rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in this run" if traffic else None,
+            "kernel": st["dominant_kernel"], "kernel_ms": ms_dom,
+            "kernel_ms_source": f"HIP events on the compute stream around every launch inside the timed loop, mean of {st['n_runs_timed']} runs",
+            "step_kernels_ms": st["ms_f32"] + st["ms_f64"], "alg_flop_per_launch": 12.0 * st["dominant_cells"],
+            "kernel_gcups": st["dominant_cells"] / (ms_dom * 1e-3) / 1e9, "hbm": hbm,
+            "note": "12 flop per cell (SURVEY.md 8d: M 4 mul + 2 add, X and Y 2 mul + 1 add) x the cells one launch processes, against the "
+                    "fp32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s = 2 cycles per wave64 v_fma_f32 per SIMD; packed fp32 has the "
+                    "same peak); `traffic` is HBM bytes per launch"}
+    return roof
 
 
 def regions_leg(pkg, synth, local_rank, lanes):
@@ -434,7 +462,10 @@ def mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_ove
     prepared = pkg.pairhmm.make_input(d)
     lanes = args.queue_lanes or max(2, min(8, host_cores() // world))
     q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
-    recs, L = synth.gen_sortdedup_packed_fast(max(args.sort_records // world, 1_000_000), 0x5EED0004 + rank, threads=host_threads(world))
+    # "interleave config-3 batches with 8 coordinate-range shards of config 4": a GPU's share of
+    # the record set is one eighth of configs[3] (25 M records), whatever the number of ranks of THIS run
+    n_rec = max(args.sort_records // max(world, 8), 1_000_000) if args.sort_records else 25_000_000
+    recs, L = synth.gen_sortdedup_packed_fast(n_rec, 0x5EED0004 + rank, threads=host_threads(world))
     eng = pkg.SortDedupEngine(local_rank)
     eng.upload(L, recs)
     q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared); eng.run(); eng.stats()
@@ -460,16 +491,17 @@ def mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_ove
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         return counts[0] * d["cells"] / dt / 1e9, counts[1] * len(recs) / dt / 1e6
-    hmm_alone, _ = run_for(1.5, True, False)
-    _, sort_alone = run_for(1.5, False, True)
-    hmm_mixed, sort_mixed = run_for(3.0, True, True)
+    hmm_alone, _ = run_for(args.mixed_seconds, True, False)
+    _, sort_alone = run_for(args.mixed_seconds, False, True)
+    hmm_mixed, sort_mixed = run_for(2 * args.mixed_seconds, True, True)
     q.close(); eng.close()
     if rank != 0:
         return None
     return {"metric": "BASELINE.json configs[4]: PairHMM queue + sort/mark-duplicate pipeline co-resident, per GPU (rank 0's figures)",
             "pairhmm_queue_gcups": {"alone": hmm_alone, "mixed": hmm_mixed}, "sortmardup_mrecords_s": {"alone": sort_alone, "mixed": sort_mixed},
             "combined_utilisation": hmm_mixed / max(hmm_alone, 1e-9) + sort_mixed / max(sort_alone, 1e-9),
-            "config": {"pairs_per_gpu_window": n_local, "records_per_gpu": len(recs), "queue_lanes": lanes},
+            "config": {"pairs_per_gpu_window": n_local, "records_per_gpu": len(recs), "queue_lanes": lanes,
+                       "window_s": {"alone": args.mixed_seconds, "mixed": 2 * args.mixed_seconds}},
             "note": "two host threads per GPU, separate contexts and streams; PairHMM streamed from host memory through the work queue, "
                     "sort records resident (independent per-GPU record sets in this leg)"}
 
@@ -493,7 +525,10 @@ def main():
     ap.add_argument("--no-ragged", action="store_true", help="skip sub-run 2b (ragged lengths)")
     ap.add_argument("--no-regions", action="store_true", help="skip the row-F1 leg (1000 regions of 40 x 25)")
     ap.add_argument("--no-queue", action="store_true", help="skip the host-work-queue leg (counter-collection runs)")
-    ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[4]: PairHMM queue and sort/mark-duplicate pipeline co-resident")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the BASELINE.json configs[4] leg (PairHMM queue and sort/mark-duplicate "
+                                                             "pipeline co-resident on every GPU)")
+    ap.add_argument("--mixed", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
+    ap.add_argument("--mixed-seconds", type=float, default=1.0, help="window of each solo phase of the configs[4] leg; the co-resident phase runs twice that")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -553,7 +588,7 @@ def main():
 
     line = None
     if rank == 0:
-        roof, valu = pairhmm_rooflines(st, measured_traffic(st["dominant_kernel"]) if hi - lo == (1 << 20) else None)
+        roof = pairhmm_rooflines(st, measured_traffic(st["dominant_kernel"]) if hi - lo == (1 << 20) else None)
         line = {
             "metric": "PairHMM GCUPS", "value": value, "unit": "GCUPS", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": tmax / args.steps * 1e3,
@@ -561,7 +596,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": what, "pairs_total": total, "pairs_per_gpu": hi - lo, "read_len": 128, "hap_len": 256, "seed": hex(seed),
                        "rerun_f64_per_step": st["n_rerun_f64"], "parallelism": f"shard{world}"},
-            "roofline": roof, "valu": valu, "upload_s": upload_s,
+            "roofline": roof, "upload_s": upload_s,
         }
 
     # ---- the same shard through the host work queue: host buffers in, results in host memory out (PCIe-inclusive;
@@ -608,12 +643,12 @@ def main():
         t2 = max_over_ranks(dt2)
         b2.close()
         if rank == 0:
-            r2, v2 = pairhmm_rooflines(st2, None)
+            r2 = pairhmm_rooflines(st2, None)
             line["ragged"] = {"metric": "PairHMM GCUPS, sub-run 2b", "value": d2["cells"] * world * args.steps / t2 / 1e9, "unit": "GCUPS",
                               "ms_per_step": t2 / args.steps * 1e3, "scaling": "weak",
                               "config": {"workload": f"SURVEY.md 8d config 2b: {n2} test cases per GPU, read U[32,128] x hap U[64,256], resident",
                                          "cells_per_gpu": d2["cells"], "launches_f32": st2["n_launches_f32"], "rerun_f64_per_step": st2["n_rerun_f64"]},
-                              "roofline": r2, "valu": v2,
+                              "roofline": r2,
                               "valu_all_kernels": {"frac": 12.0 * d2["cells"] / (st2["ms_f32"] * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
                                                    "note": "all fp32 launches of a step (one per read-length class), 12 flop per cell"}}
         del d2
@@ -629,7 +664,7 @@ def main():
     sw_line = smithwaterman_leg(pkg, synth, args, rank, local_rank) if args.sw_pairs > 0 else None
     bgzf_line = bgzf_leg(pkg, synth, args, rank, local_rank) if args.bgzf_mb > 0 else None
     cli_line = cli_leg(pkg, synth, args, rank) if args.cli_records > 0 else None
-    mixed_line = mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_over_ranks) if args.mixed else None
+    mixed_line = mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_over_ranks) if not args.no_mixed else None
     if rank == 0:
         if not args.no_regions:
             line["regions"] = regions_leg(pkg, synth, local_rank, max(2, min(4, host_cores() // world)))

@@ -172,7 +172,8 @@ static int cmp_coord(const void* a_, const void* b_) {
 }
 
 static uint64_t g_bits;
-static void bit_set(uint64_t* bm, uint64_t p) { if (p < g_bits) bm[p >> 6] |= 1ull << (p & 63); }
+/* atomic OR, as the reference's bitmap::set (sortmardup/tbb/bitmap.cpp:20-29): several shards may share one bitmap */
+static void bit_set(uint64_t* bm, uint64_t p) { if (p < g_bits) __atomic_fetch_or(&bm[p >> 6], 1ull << (p & 63), __ATOMIC_RELAXED); }
 static int bit_get(const uint64_t* bm, uint64_t p) { return p < g_bits ? (int)((bm[p >> 6] >> (p & 63)) & 1) : 0; }
 
 /* out_order[k] = arrival index of the k-th output record; out_dup[i] = 1 iff record i is marked.
@@ -181,16 +182,19 @@ static int bit_get(const uint64_t* bm, uint64_t p) { return p < g_bits ? (int)((
  * mate indices) are not the records that are ORDERED (order_coord / order_arrival, n_order entries; NULL = order
  * recs themselves), and `marks` (position << 1 | reverse half) are the ends of pairs living in other shards --
  * what the reference's workers write into the one shared bitmap (main.cpp:181-192). */
-int sd_oracle_run_shard(uint64_t L, uint64_t n, const rec_t* recs, uint64_t n_order, const uint64_t* order_coord,
+/* `shared` (may be NULL): a zeroed bitmap of 4L bits (+ 2 words) owned by the caller and shared by the shards of one
+ * record set that run concurrently on the host's cores -- the reference's ONE double_pair_indicator (main.cpp:115).  A
+ * bit another shard sets there is a bit this shard's routed marks set anyway, so results do not depend on timing. */
+int sd_oracle_run_shard_shared(uint64_t L, uint64_t n, const rec_t* recs, uint64_t n_order, const uint64_t* order_coord,
                         const uint32_t* order_arrival, uint64_t n_marks, const uint64_t* marks, uint32_t* out_order,
-                        uint8_t* out_dup, uint64_t* counts) {
+                        uint8_t* out_dup, uint64_t* counts, uint64_t* shared) {
     pair_t* dbl = (pair_t*)malloc(sizeof(pair_t) * (n / 2 + 1));
     pair_t* sgl = (pair_t*)malloc(sizeof(pair_t) * (n + 1));
     uint64_t nd = 0, ns = 0;
     /* the reference allocates 4L bits (main.cpp:115) and asserts on anything beyond; positions
      * >= 4L (only reachable through wrapped "negative" 5' ends) are ignored here and in the product */
     const uint64_t maxbit = 4 * L;
-    uint64_t* indicator = (uint64_t*)calloc((maxbit >> 6) + 2, 8);
+    uint64_t* indicator = shared ? shared : (uint64_t*)calloc((maxbit >> 6) + 2, 8);
     g_bits = maxbit;
     memset(out_dup, 0, n);
     for (uint64_t i = 0; i < n_marks; i++) bit_set(indicator, (marks[i] >> 1) + ((marks[i] & 1) ? L : 0));
@@ -250,8 +254,14 @@ int sd_oracle_run_shard(uint64_t L, uint64_t n, const rec_t* recs, uint64_t n_or
     for (uint64_t i = 0; i < no; i++) out_order[i] = ck[i].idx;
     for (uint64_t i = 0; i < n; i++) ndup += out_dup[i];
     if (counts) { counts[0] = nd; counts[1] = ns; counts[2] = ndup; }
-    free(ck); free(indicator); free(dbl); free(sgl);
+    free(ck); if (!shared) free(indicator); free(dbl); free(sgl);
     return 0;
+}
+
+int sd_oracle_run_shard(uint64_t L, uint64_t n, const rec_t* recs, uint64_t n_order, const uint64_t* order_coord,
+                        const uint32_t* order_arrival, uint64_t n_marks, const uint64_t* marks, uint32_t* out_order,
+                        uint8_t* out_dup, uint64_t* counts) {
+    return sd_oracle_run_shard_shared(L, n, recs, n_order, order_coord, order_arrival, n_marks, marks, out_order, out_dup, counts, NULL);
 }
 
 int sd_oracle_run(uint64_t L, uint64_t n, const rec_t* recs, uint32_t* out_order, uint8_t* out_dup,

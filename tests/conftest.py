@@ -126,8 +126,9 @@ class SortDedupOracle:
         return order, dup, counts
 
 
-    def run_shard(self, L, sh):
-        """sh: dict from Routed.shard_arrays() -> (order over global arrival indices, dup per marking record)."""
+    def run_shard(self, L, sh, shared_bitmap=None):
+        """sh: dict from Routed.shard_arrays() -> (order over global arrival indices, dup per marking record).
+        shared_bitmap: a zeroed uint64 array of (4L >> 6) + 2 words that concurrently running shards share."""
         n, no, nm = len(sh["mark_recs"]), len(sh["order_coord"]), len(sh["marks"])
         order = np.zeros(no, dtype=np.uint32)
         dup = np.zeros(n, dtype=np.uint8)
@@ -135,8 +136,9 @@ class SortDedupOracle:
         keep = [np.ascontiguousarray(sh[k]) for k in ("mark_recs", "order_coord", "order_arrival", "marks")]
         # an empty ordering half must still be "given": pass a valid pointer
         oc = keep[1] if no else np.zeros(1, dtype=np.uint64)
-        self.lib.sd_oracle_run_shard(ctypes.c_uint64(L), ctypes.c_uint64(n), P(keep[0]), ctypes.c_uint64(no), P(oc), P(keep[2]),
-                                     ctypes.c_uint64(nm), P(keep[3]), P(order), P(dup), None)
+        self.lib.sd_oracle_run_shard_shared(ctypes.c_uint64(L), ctypes.c_uint64(n), P(keep[0]), ctypes.c_uint64(no), P(oc), P(keep[2]),
+                                            ctypes.c_uint64(nm), P(keep[3]), P(order), P(dup), None,
+                                            None if shared_bitmap is None else shared_bitmap.ctypes.data_as(ctypes.c_void_p))
         return order, dup
 
 

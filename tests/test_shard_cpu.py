@@ -124,3 +124,69 @@ def test_route_degenerate_inputs(pkg, sd_oracle, synth):
     for k_shards in (1, 5, 64):
         order, dup, info = sharded(pkg, lambda rr, k, sh: sd_oracle.run_shard(L, sh), L, recs, k_shards)
         assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
+
+
+def _rank_cases(pkg, synth):
+    """The record sets of the multi-process test, the same on every rank (seeded / hand-made)."""
+    return [load_golden()[0], boundary_case(synth),
+            synth.gen_sortdedup_raw(2500, 31, n_contigs=3, contig_len=30_000, dup_rate=0.3, cross_contig_rate=0.2)]
+
+
+def _route_worker(rank, world, port, tmp):
+    """One process per shard, as bench.py --gpus N runs them: the rank routes the WHOLE record set with
+    only_shard = rank (sortmardup/tbb/range_partitioner.h:98-100: partition = key / range), runs the per-shard
+    pipeline on its own shard (the CPU oracle standing in for the device) and merges its piece into full-size
+    arrays; rank 0 collects the pieces -- a sum of disjoint order slices and an OR of the flags, which is all
+    mgx_sortdedup_merge leaves to do across processes."""
+    import importlib
+    import os
+    import sys
+    from conftest import PKG, ROOT
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import SortDedupOracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module(PKG)
+    orc = SortDedupOracle()
+    for c, raw in enumerate(_rank_cases(pkg, pkg.synth)):
+        recs, idx, L = pkg.sortdedup.pack(raw)
+        routed = pkg.Routed(L, recs, world, only_shard=rank)
+        sh = routed.shard_arrays(rank)
+        o, d = orc.run_shard(L, sh)
+        order = np.zeros(len(recs), dtype=np.uint32); dup = np.zeros(len(recs), dtype=np.uint8)
+        routed.merge(rank, o, d, order, dup)
+        # a rank holds nothing of the other shards
+        other = routed.shard((rank + 1) % world)
+        assert not other.order_coord and not other.mark_recs and not other.marks
+        routed.close()
+        n_order = torch.tensor([len(sh["order_coord"]), len(sh["marks"])], dtype=torch.int64)
+        t_order = torch.from_numpy(order.astype(np.int64)); t_dup = torch.from_numpy(dup.astype(np.int64))
+        dist.reduce(t_order, dst=0, op=dist.ReduceOp.SUM)
+        dist.reduce(t_dup, dst=0, op=dist.ReduceOp.MAX)
+        dist.reduce(n_order, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            np.savez(os.path.join(tmp, f"case{c}.npz"), order=t_order.numpy().astype(np.uint32), dup=t_dup.numpy().astype(np.uint8),
+                     n_order=n_order.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_route_their_own_shard_gloo(tmp_path, pkg, sd_oracle, synth):
+    """the N > 1 path of the sortmardup leg with one PROCESS per shard (world size 2, gloo)."""
+    import os
+    import torch.multiprocessing as mp
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_route_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    n_marks = []
+    for c, raw in enumerate(_rank_cases(pkg, synth)):
+        recs, idx, L = pkg.sortdedup.pack(raw)
+        want_order, want_dup, _ = sd_oracle.run(L, recs)
+        got = np.load(tmp_path / f"case{c}.npz")
+        assert int(got["n_order"][0]) == len(recs)                    # every record ordered by exactly one rank
+        assert np.array_equal(got["order"], want_order), f"case {c}: order"
+        assert np.array_equal(got["dup"], want_dup), f"case {c}: duplicate flags"
+        n_marks.append(int(got["n_order"][1]))
+    assert n_marks[1] == 2                                            # the boundary case's two routed marks crossed ranks
