@@ -59,6 +59,7 @@ struct Bin {
     // launch geometry
     uint32_t block = 256, lds_stride = 0, grid_f32 = 0, grid_f64 = 0, grid_f64_all = 0;
     bool strip = false;              // reads longer than 1024 bases: the strip-mined kernel, one test case per workgroup
+    bool pk = false;                 // fp32 launches use the packed kernel (pairhmm_fwd_pk<G, RPL / 2>): even RPL <= 8, G <= 16
 };
 
 }  // namespace
@@ -173,7 +174,8 @@ inline void shape_of(uint32_t R, int* G, int* RPL) {
 // dynamic LDS of one block: per-wavefront emission table (fp32 only) + per-group haplotype codes
 inline uint32_t lds_bytes(const Bin& bin, bool f32) {
     const uint32_t waves = bin.block / 64u, groups = bin.block / (uint32_t)(f32 ? bin.G : bin.Gd);
-    const uint32_t etab = f32 ? (uint32_t)((bin.RPL + 1) / 2) * kNumCodes * 512u : 0u;
+    uint32_t etab = f32 ? (uint32_t)((bin.RPL + 1) / 2) * kNumCodes * 512u : 0u;
+    if (f32 && bin.pk) etab = (uint32_t)((bin.RPL * kPkRowStride + 15) & ~15);
     return waves * etab + groups * bin.lds_stride;
 }
 // bins in order of (G, RPL): [G=4: 1..8][G=8: 1..8][G=16: 1..12][G=64: 4..16]
@@ -198,9 +200,13 @@ inline void bin_shape(int k, Bin* b) {
 constexpr uint64_t kMergeBelow = 4096;
 
 // launch geometry of a bin once job_count and max_h are known
-int finalize_bin(Bin& bin, int n_cu) {
+int finalize_bin(Bin& bin, int n_cu, unsigned ctx_flags) {
     // LDS per group: G pad + codes + G pad + prefetch slack (see the kernel's staging loop)
-    bin.lds_stride = (bin.max_h + 2u * (uint32_t)std::max(bin.G, bin.Gd) + 8u + 15u) & ~15u;
+    // the packed fp32 kernel is opt-in: context flag MGX_PAIRHMM_PACKED_FP32 or MGX_PAIRHMM_PK=1
+    static const int pk_mode = [] { const char* e = getenv("MGX_PAIRHMM_PK"); return e ? atoi(e) : 0; }();
+    bin.pk = (pk_mode != 0 || (ctx_flags & MGX_PAIRHMM_PACKED_FP32)) && !bin.strip && bin.G <= 16 && bin.RPL % 2 == 0 && bin.RPL <= 8;
+    // (the packed kernel's half-lanes need 2G pad codes on either side of the haplotype, the scalar one G)
+    bin.lds_stride = (bin.max_h + (bin.pk ? 4u : 2u) * (uint32_t)std::max(bin.G, bin.Gd) + 8u + 15u) & ~15u;
     bin.block = 64;                   // one wavefront per workgroup: finest LDS/VGPR packing per CU, no cross-wave
                                       // barriers; in-process A/B at 1 M pairs: 5.48 ms (64), 5.65 (128), 5.46 (256)
     if (const char* e = getenv("MGX_PAIRHMM_BLOCK")) { const int v = atoi(e); if (v == 64 || v == 128 || v == 256) bin.block = (uint32_t)v; }
@@ -502,7 +508,7 @@ int create_cross(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, mgx_pairhmm_ba
         bin.max_h = max_h;
         bin.cells = sumR_bin[k] * sumH;
         bin.alg_bytes = 5 * sumR_bin[k] * nh + reads_in[k] * (sumH + 4 * nh);
-        if ((rc = finalize_bin(bin, c->n_cu))) return rc;
+        if ((rc = finalize_bin(bin, c->n_cu, c->flags))) return rc;
         hipLaunchKernelGGL(pairhmm_make_jobs, dim3((bin.job_count + 255) / 256), dim3(256), 0, s,
                            (const SeqRef*)(dv + o_rtab) + rstart[k], (const SeqRef*)(dv + o_htab), (uint32_t)nh,
                            bin.job_count, b->d_jobs + job_begin);
@@ -702,7 +708,7 @@ int create_cross_multi(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_pairhmm_i
         bin.max_h = max_h;
         bin.cells = cells_in[k];
         bin.alg_bytes = bytes_in[k];
-        if ((rc = finalize_bin(bin, c->n_cu))) return rc;
+        if ((rc = finalize_bin(bin, c->n_cu, c->flags))) return rc;
         b->stats.cells += bin.cells; b->stats.alg_bytes += bin.alg_bytes;
         b->bins.push_back(bin);
         job_begin += bin.job_count;
@@ -827,7 +833,7 @@ int create_pairs(mgx_pairhmm_t* c, const mgx_pairhmm_input_t* in, const mgx::Pac
                 bin.cells += (uint64_t)jobs[q].R * jobs[q].H;
                 bin.alg_bytes += 5ull * jobs[q].R + jobs[q].H + 4;
             }
-            if ((rc = finalize_bin(bin, c->n_cu))) return rc;
+            if ((rc = finalize_bin(bin, c->n_cu, c->flags))) return rc;
             b->bins.push_back(bin);
         }
     }
@@ -988,7 +994,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
                 m.block_first[q] = blocks; blocks += bn.grid_f32;
                 m.job_first[q] = bn.job_begin; m.job_count[q] = bn.job_count; m.lds_stride[q] = bn.lds_stride;
                 m.G[q] = (uint8_t)bn.G; m.RPL[q] = (uint8_t)bn.RPL;
-                lds = std::max(lds, lds_bytes(bn, true));
+                { Bin sc = bn; sc.pk = false; lds = std::max(lds, lds_bytes(sc, true)); }      // the multi-class kernel runs the scalar bodies
                 if (bn.cells > b->bins[book].cells) book = set[q];
                 cells += bn.cells; bytes += bn.alg_bytes;
                 in_multi[set[q]] = 1;
@@ -1032,7 +1038,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
         if (!force_f64 && !in_multi[k]) {
             a.job_list = nullptr; a.n_dyn = nullptr; a.n_static = bin.job_count;
             a.ph2pr = c->d_ph2pr_f; a.mm = c->d_mm_f; a.ph2pr_div3 = c->d_div3_f; a.gap_ratio = c->d_ratio_f;
-            KernelFn f = bin.strip ? (KernelFn)pairhmm_fwd_strip<float> : pick_kernel<float>(bin.G, bin.RPL);
+            KernelFn f = bin.strip ? (KernelFn)pairhmm_fwd_strip<float> : bin.pk ? pick_kernel_pk(bin.G, bin.RPL / 2) : pick_kernel<float>(bin.G, bin.RPL);
             if (!f) { set_error("no fp32 kernel for G=%d RPL=%d", bin.G, bin.RPL); return -ENOSYS; }
             if (timing) HIP_TRY(hipEventRecord(ev[4 * k + 0], sk));
             hipLaunchKernelGGL(f, dim3(bin.grid_f32), dim3(bin.block), lds_bytes(bin, true), sk, a);
@@ -1157,6 +1163,7 @@ int mgx_pairhmm_batch_stats(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b, mgx_pairhm
             st.dominant_cells = cells_of(dom);
             st.dominant_alg_bytes = acct ? b->acct_bytes[dom] : b->bins[dom].alg_bytes;
             if (acct && b->acct_multi[dom]) snprintf(st.dominant_kernel, sizeof st.dominant_kernel, "pairhmm_fwd_multi<%d>", b->acct_multi[dom] - 1);
+            else if (b->bins[dom].pk) snprintf(st.dominant_kernel, sizeof st.dominant_kernel, "pairhmm_fwd_pk<%d, %d>", b->bins[dom].G, b->bins[dom].RPL / 2);
             else snprintf(st.dominant_kernel, sizeof st.dominant_kernel, "pairhmm_fwd<float, %d, %d>", b->bins[dom].G, b->bins[dom].RPL);
         }
         b->runs_timed = 0;

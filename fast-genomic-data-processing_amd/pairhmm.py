@@ -12,6 +12,7 @@ from . import native
 
 FORCE_DOUBLE = 1
 TIMING = 2
+PACKED_FP32 = 4      # the packed fp32 kernel for classes with an even number of rows per lane (bit-identical, slower: DESIGN.md 3.7)
 
 
 def _ptr(a):

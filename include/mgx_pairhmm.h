@@ -50,6 +50,10 @@ typedef struct mgx_pairhmm_batch mgx_pairhmm_batch_t;
 /* flags for mgx_pairhmm_create */
 #define MGX_PAIRHMM_FORCE_DOUBLE 1u /* PairHMMNativeArgumentCollection.useDoublePrecision */
 #define MGX_PAIRHMM_TIMING       2u /* record HIP events around every kernel launch */
+#define MGX_PAIRHMM_PACKED_FP32  4u /* classes with an even number of rows per lane run pairhmm_fwd_pk (two rows per v_pk_*_f32
+                                     * instruction).  Bit-identical results; measured SLOWER than the default kernel on every
+                                     * shape (a packed instruction occupies the fp32 pipe as long as two scalar
+                                     * ones), so it is off unless asked for (or MGX_PAIRHMM_PK=1) */
 /* bits 8..15 (both mgx_pairhmm_create and mgx_sortdedup_create): optional CU partition, an 8-bit
  * pattern repeated over the CU index; 0 or 0xFF = all CUs.  MGX_CU_PATTERN(0x3F) keeps 6 CUs of 8. */
 #define MGX_CU_PATTERN(p) (((unsigned)(p) & 0xFFu) << 8)

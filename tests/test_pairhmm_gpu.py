@@ -318,3 +318,43 @@ def test_results_near_the_flush_to_zero_threshold(pkg, engine, oracle):
     out64, _, st64 = run(eng64, d)
     eng64.close()
     assert np.array_equal(out64, out) and st64["n_exact"] == st["n_exact"]
+
+
+def test_packed_kernel_is_bit_identical_to_the_scalar_kernel(pkg, oracle, synth):
+    """Round 3: with MGX_PAIRHMM_PACKED_FP32 the classes with an even number of rows per lane run
+    pairhmm_fwd_pk (two rows per v_pk_* instruction, the high half of a lane one column behind the low half; opt-in because
+    it measured slower).  Every cell is computed by the same operations in the same order as
+    in the default kernel, so the two must agree bit for bit -- over every lane-group width and row count, with 'N' in
+    either sequence, reads shorter than a half-lane, haplotypes shorter than the fill/drain."""
+    scalar = pkg.PairHMMEngine(0)
+    packed = pkg.PairHMMEngine(0, flags=pkg.pairhmm.PACKED_FP32)
+    for seed, rr, hr, n in ((1, (1, 128), (1, 256), 30000), (2, (97, 128), (200, 256), 6000), (3, (1, 40), (1, 30), 8000),
+                            (4, (120, 128), (1, 12), 3000)):
+        d = synth.gen_pairhmm_pairs_fast(n, 0xBEEF00 + seed, r_range=rr, h_range=hr)
+        a = packed.compute(d)
+        b = scalar.compute(d)
+        assert np.array_equal(a, b), f"seed {seed}: {(a != b).sum()} of {n} differ"
+        want, _ = oracle.batch(d)
+        assert_log10_close(a, want)
+    # shared reads / haplotypes (a region) and the cross-product form
+    d = synth.gen_pairhmm_region(64, 40, 99, r_range=(20, 128), h_range=(30, 256))
+    assert np.array_equal(packed.compute(d), scalar.compute(d))
+    # a gap-continuation byte of 0 (pGAPM == 0) sends the test case to the double-precision list of the packed kernel;
+    # the scalar kernel keeps it in fp32 (plain form): both within tolerance of the oracle, the other test cases identical
+    d = synth.gen_pairhmm_pairs_fast(4000, 0xBEEF10, r_range=(30, 128), h_range=(40, 256))
+    gcp = d["gcp"].copy()
+    ro = d["read_off"].astype(np.int64)
+    hit = np.zeros(4000, dtype=bool)
+    for i in range(0, 4000, 37):
+        gcp[ro[i] + (i % int(ro[i + 1] - ro[i]))] = 0 if i % 2 else 128
+        hit[i] = True
+    d2 = dict(d, gcp=gcp)
+    a, ua = packed.batch(d2), None
+    a.run(); av, au = a.results(with_flags=True); a.close()
+    bv = scalar.compute(d2)
+    want, _ = oracle.batch(d2)
+    assert_log10_close(av, want); assert_log10_close(bv, want)
+    pr = d2["pair_read"]
+    assert au[hit[pr]].all()                                    # computed in double
+    assert np.array_equal(av[~hit[pr]], bv[~hit[pr]])
+    scalar.close(); packed.close()
