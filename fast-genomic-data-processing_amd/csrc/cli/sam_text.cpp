@@ -194,6 +194,9 @@ bool parse_record(const char* line, size_t len, const Header& h, Record* r, std:
             num = 0; have = false;
         }
         if (have) { *err = "bad CIGAR"; return false; }
+        // n_cigar_op is 16 bits in BAM; htslib writes longer CIGARs as a kSmN placeholder plus a CG:B,I tag (SAMv1 4.2.2),
+        // which this tool does not produce: reject instead of writing a record every reader would mis-slice
+        if (r->cigar.size() > 65535) { *err = "more than 65535 CIGAR operations"; return false; }
     }
     if (n[6] == 1 && f[6][0] == '=') r->mtid = r->tid;
     else if (n[6] == 1 && f[6][0] == '*') r->mtid = -1;
@@ -266,6 +269,7 @@ bool parse_record_into(const char* line, size_t len, const Header& h, Parsed* ou
         if (have) return bad("bad CIGAR");
     }
     const size_t n_cig = cigar->size() - cigar0;
+    if (n_cig > 65535) return bad("more than 65535 CIGAR operations");      // see parse_record
     const int32_t rec_end = (int32_t)(pos + (ref_len > 0 ? ref_len : 1));
     int32_t mtid;
     if (n[6] == 1 && f[6][0] == '=') mtid = tid;

@@ -962,7 +962,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
     // (reads of 20-32 bases: 2764 -> 3009; region-sized batches).  MGX_PAIRHMM_MULTI: 0 never, 1 small classes (default),
     // 2 the same with the build forced to 4 wavefronts per SIMD, 3 every narrow class.
     static const int multi_mode = [] { const char* e = getenv("MGX_PAIRHMM_MULTI"); return e ? atoi(e) : 1; }();
-    const uint32_t multi_below = multi_mode == 3 ? 0xFFFFFFFFu : (uint32_t)c->n_cu * 64u;     // workgroups; ~5 device fills
+    const uint32_t multi_below = (multi_mode == 3 || multi_mode == 4) ? 0xFFFFFFFFu : (uint32_t)c->n_cu * 64u;     // workgroups; ~5 device fills
     const bool multi_ok = multi_mode != 0;
     std::vector<char> in_multi(b->bins.size(), 0);
     b->acct_cells.assign(b->bins.size(), 0); b->acct_bytes.assign(b->bins.size(), 0); b->acct_multi.assign(b->bins.size(), 0);
@@ -1004,7 +1004,7 @@ int mgx_pairhmm_batch_run(mgx_pairhmm_t* c, mgx_pairhmm_batch_t* b) {
             b->acct_cells[book] = cells; b->acct_bytes[book] = bytes; b->acct_multi[book] = (int8_t)(1 + gset);
             if (timing) for (size_t q : set) if (q != book) { HIP_TRY(hipEventRecord(ev[4 * q + 0], s)); HIP_TRY(hipEventRecord(ev[4 * q + 1], s)); }
             if (timing) HIP_TRY(hipEventRecord(ev[4 * book + 0], s));
-            if (multi_mode == 2) {
+            if (multi_mode == 2 || multi_mode == 4) {
                 if (gset == 0) hipLaunchKernelGGL(pairhmm_fwd_multi_occ4<0>, dim3(blocks), dim3(64), lds, s, m);
                 else           hipLaunchKernelGGL(pairhmm_fwd_multi_occ4<1>, dim3(blocks), dim3(64), lds, s, m);
             } else {

@@ -278,3 +278,53 @@ def test_cli_usage_and_build(pkg):
     exe = build_cli()
     res = subprocess.run([exe], capture_output=True, text=True)
     assert res.returncode == 2 and "usage" in res.stderr
+
+
+@pytest.mark.gpu
+def test_cli_on_the_sam_files_the_reference_holds(tmp_path, sd_oracle):
+    """the SAM files of the reference's vendored htslib test suite (tests/golden/sam_vectors.npz) through
+    the whole tool: every field of every record as an independent spec-based parser reads it from the text, in the oracle's
+    order with the oracle's duplicate flags; the BAM + BAI pass the checker that is pinned on htslib-written files
+    (tests/test_sam_vectors.py); for index.sam the index has the structure of the reference-held index.bam.bai."""
+    import json
+    import sam_spec
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sam_vectors.npz"))
+    exp = json.loads(bytes(z["expected_json"]).decode())
+    for key in z.files:
+        if not key.startswith("sam:"):
+            continue
+        name = key[4:]
+        want = exp[name]
+        if not want["refs"]:
+            continue                                    # a SAM file without @SQ lines cannot become a BAM
+        sam, bam = str(tmp_path / "in.sam"), str(tmp_path / "out.bam")
+        open(sam, "wb").write(bytes(z[key]))
+        res = subprocess.run([build_cli(), "-I", sam, "-O", bam, "-t", "3"], capture_output=True, text=True)
+        assert res.returncode == 0, f"{name}: {res.stderr}"
+        raw_bam = open(bam, "rb").read()
+        data = gzip.decompress(raw_bam)
+        text, refs, p0 = sam_spec.decode_bam_header(data)
+        assert text == want["header"] and refs == [tuple(r) for r in want["refs"]], name
+        got = sam_spec.decode_bam_records(data, p0)
+        recs = [dict(r, qual=np.asarray(r["qual"], dtype=np.uint8)) for r in want["records"]]
+        orecs, idx, L = sd_oracle.pack(raw_from_recs(recs, [r[1] for r in want["refs"]]))
+        order, dup, _ = sd_oracle.run(L, orecs)
+        assert len(got) == len(recs), name
+        for k, g in enumerate(got):
+            src = want["records"][idx[order[k]]]
+            assert g["flag"] == src["flag"] | (0x400 if dup[order[k]] else 0), (name, k)
+            for f in ("qname", "tid", "pos", "mapq", "cigar", "mtid", "mpos", "tlen", "seq", "qual"):
+                assert g[f] == src[f], (name, k, f)
+            assert len(g["aux"]) == len(src["aux"]) and all(a[:2] == b[:2] for a, b in zip(g["aux"], src["aux"])), (name, k)
+        bai = open(bam + ".bai", "rb").read()
+        n_indexed = sam_spec.check_index(raw_bam, bai)
+        assert n_indexed == sum(1 for r in recs if r["tid"] >= 0), name
+        if name == "index.sam":
+            mine, my_nocoor = sam_spec.parse_bai(bai)
+            theirs, their_nocoor = sam_spec.parse_bai(bytes(z["bin:index.bam.bai"]))
+            assert len(mine) == len(theirs) and my_nocoor == their_nocoor
+            for ref, (a, b) in enumerate(zip(mine, theirs)):
+                assert set(a["bins"]) - {37450} == set(b["bins"]) - {37450}, ref       # the same bins are populated
+                assert len(a["linear"]) == len(b["linear"]), ref                        # the same 16 kbp windows are covered
+                if 37450 in a["bins"] and 37450 in b["bins"]:
+                    assert a["bins"][37450][1] == b["bins"][37450][1], ref              # mapped / unmapped record counts
