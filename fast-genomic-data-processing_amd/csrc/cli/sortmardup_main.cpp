@@ -259,17 +259,46 @@ int main(int argc, char** argv) {
     // while the first slices are already being parsed; a parser waits for them only when it has bytes for the device.
     mgx_bgzf_t* zctx = nullptr; mgx_bgzf_store_t* store = nullptr;
     mgx_sortdedup_t* sd = nullptr;
-    const bool use_store = out_mode == kOutDevice;
+    bool use_store = out_mode == kOutDevice;
     std::mutex gpu_mu; std::condition_variable gpu_cv; int gpu_state = 0;          // 0 starting, 1 ready, -1 failed
     std::string gpu_error;
     std::thread gpu_init([&]() {
         bool ok = true;
-        if (use_store && (mgx_bgzf_create(device, 0, &zctx) || mgx_bgzf_store_create(zctx, &store))) ok = false;
+        const bool tr = getenv("MGX_CLI_TRACE") != nullptr;
+        const auto i0 = clk::now();
+        auto since = [&]() { return std::chrono::duration<double>(clk::now() - i0).count(); };
+        // What the parsers wait for comes first: the record store (runtime start, streams, the first piece of HBM) and the
+        // sort context; the compressor's own state is set up afterwards, while the text is being parsed.
+        if (use_store && file_bytes) {
+            // -z device keeps every BAM byte in HBM next to the sort's buffers; when the input cannot fit, say so now and keep
+            // the bytes in host memory instead of failing in the middle of the ingest.  BAM bytes are about half
+            // the SAM text; the sort and the emit need about 100 bytes per record of ~360 text bytes on top.
+            uint64_t free_b = 0, total_b = 0;
+            if (mgx_bgzf_device_memory(device, &free_b, &total_b) == 0) {
+                if (const char* e = getenv("MGX_CLI_DEVICE_FREE")) free_b = strtoull(e, nullptr, 10);      // tests: pretend
+                const uint64_t need = file_bytes * 6 / 10 + (file_bytes / 360) * 100 + (1ull << 30);
+                if (need > free_b) {
+                    fprintf(stderr, "sortmardup: about %.1f GB of device memory needed for -z device, %.1f GB free: keeping the BAM bytes in host memory (-z pinned)\n",
+                            need / 1e9, free_b / 1e9);
+                    use_store = false; out_mode = kOutPinned;
+                }
+            }
+        }
+        if (tr) fprintf(stderr, "  bring-up: runtime up, device memory known at %.3f s\n", since());
+        if (use_store && mgx_bgzf_create(device, 0, &zctx)) ok = false;
+        if (tr) fprintf(stderr, "  bring-up: compressor context at %.3f s\n", since());
+        if (ok && use_store && (mgx_bgzf_store_create(zctx, &store) || mgx_bgzf_store_reserve(store, file_bytes ? file_bytes * 6 / 10 : (1ull << 30)))) ok = false;
+        if (tr) fprintf(stderr, "  bring-up: record store ready at %.3f s\n", since());
         if (ok && (mgx_sortdedup_create(device, 0, &sd) || mgx_sortdedup_upload_begin(sd, L, file_bytes / 256))) ok = false;
-        std::lock_guard<std::mutex> g(gpu_mu);
-        if (!ok) gpu_error = mgx_last_error();
-        gpu_state = ok ? 1 : -1;
-        gpu_cv.notify_all();
+        if (tr) fprintf(stderr, "  bring-up: sort context ready at %.3f s\n", since());
+        {
+            std::lock_guard<std::mutex> g(gpu_mu);
+            if (!ok) gpu_error = mgx_last_error();
+            gpu_state = ok ? 1 : -1;
+            gpu_cv.notify_all();
+        }
+        if (ok && zctx && mgx_bgzf_prepare(zctx)) fprintf(stderr, "sortmardup: %s\n", mgx_last_error());      // not fatal here: the output stage reports it
+        if (tr) fprintf(stderr, "  bring-up: compressor ready at %.3f s\n", since());
     });
     auto gpu_ready = [&]() -> bool {
         std::unique_lock<std::mutex> lk(gpu_mu);

@@ -894,6 +894,8 @@ struct mgx_bgzf {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;              // all batches of a context run in order on one stream
+    hipStream_t copy = nullptr;                // packed blocks travel back on a stream of their own, behind their batch's kernels only
+    std::mutex prep_mu; bool prepared = false; // the compressor's scratch and kernel attributes: set up at first use (or mgx_bgzf_prepare)
     u32* d_scratch = nullptr; u32 grid = 0;
     u32* d_n_stored = nullptr;
     unsigned long long* d_prof = nullptr;
@@ -908,7 +910,7 @@ struct mgx_bgzf_batch {
     u8* h_out = nullptr; u64* h_out_off = nullptr;     // pinned, results
     u8* d_in = nullptr; u64* d_off = nullptr; u8* d_slots = nullptr; u32* d_sizes = nullptr; u64* d_out_off = nullptr; u8* d_out = nullptr;
     u64 out_cap = 0;
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_off = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_off = nullptr, ev_out = nullptr;
     u32 n_blocks = 0; u64 n_in = 0;
     bool submitted = false;
 };
@@ -936,17 +938,43 @@ int mgx_bgzf_create(int device, unsigned flags, mgx_bgzf_t** out) {
     if (const char* e = getenv("MGX_BGZF_COST_BASE")) c->cost_base = (u32)atoi(e);
     if (const char* e = getenv("MGX_BGZF_COST_RLE")) c->cost_rle = (u32)atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     c->grid = (u32)c->n_cu;                       // ~94 KB of LDS per workgroup: one per CU
     if (const char* e = getenv("MGX_BGZF_GRID")) { const int v = atoi(e); if (v > 0) c->grid = (u32)v; }
+    // the compressor's own device state (scratch tables, counters, the kernel's LDS attribute -- which loads the code
+    // object) is set up by the first batch or by mgx_bgzf_prepare: a record store needs none of it, and a tool that
+    // creates the context while it parses its first input should not wait for it
+    *out = c.release();
+    return 0;
+}
+
+int mgx_bgzf_prepare(mgx_bgzf_t* c) {
+    if (!c) { set_error("NULL argument"); return -EINVAL; }
+    std::lock_guard<std::mutex> g(c->prep_mu);
+    if (c->prepared) return 0;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc((void**)&c->d_scratch, (size_t)c->grid * kScratchPerWg * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->d_n_stored, sizeof(u32)));
-    HIP_TRY(hipMemset(c->d_n_stored, 0, sizeof(u32)));
+    HIP_TRY(hipMemsetAsync(c->d_n_stored, 0, sizeof(u32), c->stream));
     if (const char* e = getenv("MGX_BGZF_PROF")) if (atoi(e)) {
         HIP_TRY(hipMalloc((void**)&c->d_prof, 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->d_prof, 0, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->d_prof, 0, 16 * sizeof(unsigned long long), c->stream));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)k_bgzf_deflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
-    *out = c.release();
+    c->prepared = true;
+    return 0;
+}
+
+int mgx_bgzf_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (!free_bytes || !total_bytes) { set_error("NULL argument"); return -EINVAL; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { set_error("no HIP device"); return -ENODEV; }
+    if (device < 0) device = 0;
+    if (device >= n_dev) { set_error("device %d of %d", device, n_dev); return -EINVAL; }
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = f; *total_bytes = t;
     return 0;
 }
 
@@ -954,6 +982,7 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     (void)hipFree(c->d_scratch);
     (void)hipFree(c->d_n_stored);
     if (c->d_prof) {
@@ -971,12 +1000,13 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
 
 void mgx_bgzf_batch_destroy(mgx_bgzf_t* c, mgx_bgzf_batch_t* b) {
     if (!b) return;
-    if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy); }
     (void)hipHostFree(b->h_in); (void)hipHostFree(b->h_off); (void)hipHostFree(b->h_out); (void)hipHostFree(b->h_out_off);
     (void)hipFree(b->d_in); (void)hipFree(b->d_off); (void)hipFree(b->d_slots); (void)hipFree(b->d_sizes); (void)hipFree(b->d_out_off); (void)hipFree(b->d_out);
     if (b->ev_k0) (void)hipEventDestroy(b->ev_k0);
     if (b->ev_k1) (void)hipEventDestroy(b->ev_k1);
     if (b->ev_off) (void)hipEventDestroy(b->ev_off);
+    if (b->ev_out) (void)hipEventDestroy(b->ev_out);
     delete b;
 }
 
@@ -989,6 +1019,7 @@ static int batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_blocks
     *out = nullptr;
     if (max_blocks == 0) { set_error("max_blocks is 0"); return -EINVAL; }
     in_capacity = std::min<u64>(in_capacity, (u64)max_blocks * kMaxIn);
+    if (const int prc = mgx_bgzf_prepare(c)) return prc;
     HIP_TRY(hipSetDevice(c->device));
     mgx_bgzf_batch* b = new (std::nothrow) mgx_bgzf_batch;
     if (!b) { set_error("out of memory"); return -ENOMEM; }
@@ -1006,7 +1037,8 @@ static int batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_blocks
     if (hipMalloc((void**)&b->d_out_off, ((size_t)max_blocks + 1) * sizeof(u64)) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&b->d_out, b->out_cap) != hipSuccess) return fail("hipMalloc");
     if (hipEventCreate(&b->ev_k0) != hipSuccess || hipEventCreate(&b->ev_k1) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_off, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
+        hipEventCreateWithFlags(&b->ev_off, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
     b->h_off[0] = 0;
     *out = b;
     return 0;
@@ -1060,10 +1092,13 @@ int mgx_bgzf_batch_wait(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, const uint8_t** out,
     HIP_TRY(hipEventSynchronize(b->ev_off));
     const u64 total = b->h_out_off[b->n_blocks];
     if (total > b->out_cap) { set_error("internal: %llu output bytes exceed the bound %llu", (unsigned long long)total, (unsigned long long)b->out_cap); return -EIO; }
-    // the packed blocks: exactly their bytes (the copy is ordered behind later batches' kernels on the stream; with
-    // two or three batches in flight the link is busy either way)
-    HIP_TRY(hipMemcpyAsync(b->h_out, b->d_out, total, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the packed blocks: exactly their bytes, on the copy stream behind THIS batch's kernels only -- on the kernel stream
+    // the copy would queue behind the deflate kernels of the batches submitted since, and waiting for it would drain them
+    // (the device then idles while the caller writes this batch out)
+    HIP_TRY(hipStreamWaitEvent(c->copy, b->ev_k1, 0));
+    HIP_TRY(hipMemcpyAsync(b->h_out, b->d_out, total, hipMemcpyDeviceToHost, c->copy));
+    HIP_TRY(hipEventRecord(b->ev_out, c->copy));
+    HIP_TRY(hipEventSynchronize(b->ev_out));
     float ms = 0;
     if (hipEventElapsedTime(&ms, b->ev_k0, b->ev_k1) == hipSuccess) c->ms_kernels = ms;
     c->n_blocks += b->n_blocks; c->bytes_in += b->n_in; c->bytes_out += total;
@@ -1130,23 +1165,41 @@ struct mgx_bgzf_store {
     static constexpr int kStage = 24;
     static constexpr size_t kStageBytes = 4u << 20;
     hipStream_t copy[kStage] = {};
-    u8* stage[kStage] = {};
+    u8* stage[kStage] = {};                    // pinned, allocated by the first put that takes the slot (in parallel, off create's path)
     std::mutex stage_mu; std::condition_variable stage_cv;
     std::vector<int> stage_free;
 };
 
 int mgx_bgzf_store_create(mgx_bgzf_t* c, mgx_bgzf_store_t** out) {
     if (!c || !out) { set_error("NULL argument"); return -EINVAL; }
+    *out = nullptr;
     mgx_bgzf_store* st = new (std::nothrow) mgx_bgzf_store;
     if (!st) { set_error("out of memory"); return -ENOMEM; }
     st->ctx = c;
-    HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < mgx_bgzf_store::kStage; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&st->copy[i], hipStreamNonBlocking));
-        HIP_TRY(hipHostMalloc((void**)&st->stage[i], mgx_bgzf_store::kStageBytes, hipHostMallocDefault));
-        st->stage_free.push_back(i);
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) {
+        set_error("record store: %s", hipGetErrorString(e));
+        mgx_bgzf_store_destroy(st);
+        return -EIO;
     }
+    // a slot's stream and pinned buffer are made by the first put that takes the slot: in parallel on the callers'
+    // threads instead of 24 stream creations and 96 MB of page pinning in front of the first put
+    for (int i = 0; i < mgx_bgzf_store::kStage; ++i) st->stage_free.push_back(mgx_bgzf_store::kStage - 1 - i);
     *out = st;
+    return 0;
+}
+
+// Allocates HBM for about `bytes` more record bytes now (1 GB pieces), so that the puts of the first slices do not wait
+// for hipMalloc one after the other.
+int mgx_bgzf_store_reserve(mgx_bgzf_store_t* st, uint64_t bytes) {
+    if (!st) { set_error("NULL argument"); return -EINVAL; }
+    HIP_TRY(hipSetDevice(st->ctx->device));
+    std::lock_guard<std::mutex> g(st->mu);
+    if (!st->chunks.empty() || bytes == 0) return 0;
+    const u64 cap = std::min<u64>(std::max<u64>((bytes + 15) & ~15ull, 64ull << 20), 256ull << 20);      // a first piece that is quick to map
+    u8* p = nullptr;
+    if (hipMalloc((void**)&p, cap) != hipSuccess) { set_error("hipMalloc of %llu bytes for the record store failed", (unsigned long long)cap); return -ENOMEM; }
+    st->chunks.push_back(p); st->cur_off = 0; st->cur_cap = cap;
     return 0;
 }
 
@@ -1161,6 +1214,7 @@ void mgx_bgzf_store_destroy(mgx_bgzf_store_t* st) {
 
 int mgx_bgzf_store_put(mgx_bgzf_store_t* st, const uint8_t* bytes, uint64_t n, uint64_t* addr) {
     if (!st || !addr || (n && !bytes)) { set_error("NULL argument"); return -EINVAL; }
+    if (n == 0) { *addr = 0; return 0; }           // nothing to store (a slice of blank lines); no chunk is touched
     HIP_TRY(hipSetDevice(st->ctx->device));
     u8* dst;
     {
@@ -1183,8 +1237,13 @@ int mgx_bgzf_store_put(mgx_bgzf_store_t* st, const uint8_t* bytes, uint64_t n, u
             k = st->stage_free.back(); st->stage_free.pop_back();
         }
         const u64 piece = std::min<u64>(mgx_bgzf_store::kStageBytes, n - done);
-        memcpy(st->stage[k], bytes + done, piece);
-        hipError_t e = hipMemcpyAsync(dst + done, st->stage[k], piece, hipMemcpyHostToDevice, st->copy[k]);
+        hipError_t e = hipSuccess;
+        if (!st->copy[k]) e = hipStreamCreateWithFlags(&st->copy[k], hipStreamNonBlocking);                                     // this slot's first use
+        if (e == hipSuccess && !st->stage[k]) e = hipHostMalloc((void**)&st->stage[k], mgx_bgzf_store::kStageBytes, hipHostMallocDefault);
+        if (e == hipSuccess) {
+            memcpy(st->stage[k], bytes + done, piece);
+            e = hipMemcpyAsync(dst + done, st->stage[k], piece, hipMemcpyHostToDevice, st->copy[k]);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(st->copy[k]);
         { std::lock_guard<std::mutex> g(st->stage_mu); st->stage_free.push_back(k); }
         st->stage_cv.notify_one();
@@ -1281,7 +1340,7 @@ int mgx_bgzf_stats(mgx_bgzf_t* c, mgx_bgzf_stats_t* out) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     u32 ns = 0;
-    HIP_TRY(hipMemcpy(&ns, c->d_n_stored, sizeof ns, hipMemcpyDeviceToHost));
+    if (c->d_n_stored) HIP_TRY(hipMemcpy(&ns, c->d_n_stored, sizeof ns, hipMemcpyDeviceToHost));
     out->n_blocks = c->n_blocks; out->bytes_in = c->bytes_in; out->bytes_out = c->bytes_out; out->n_stored = ns; out->ms_kernels = c->ms_kernels;
     return 0;
 }

@@ -202,6 +202,9 @@ BGZF_SYMBOLS = {
     "mgx_bgzf_bound": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "mgx_bgzf_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mgx_bgzf_stats": (C.c_int, [C.c_void_p, C.POINTER(BgzfStats)]),
+    "mgx_bgzf_prepare": (C.c_int, [C.c_void_p]),
+    "mgx_bgzf_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "mgx_bgzf_store_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
     "mgx_bgzf_store_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mgx_bgzf_store_destroy": (None, [C.c_void_p]),
     "mgx_bgzf_store_put": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),

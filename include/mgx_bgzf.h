@@ -34,6 +34,11 @@ const char* mgx_last_error(void);
 
 int mgx_bgzf_create(int device, unsigned flags, mgx_bgzf_t** out);
 void mgx_bgzf_destroy(mgx_bgzf_t* ctx);
+/* Optional: sets up the compressor's device state (scratch, kernel attributes) now instead of at the first batch, e.g. on
+ * a bring-up thread while the caller parses its input.  mgx_bgzf_create itself only starts the runtime and two streams. */
+int mgx_bgzf_prepare(mgx_bgzf_t* ctx);
+/* Free and total device memory, for a caller that has to choose between keeping its records in HBM and in host memory. */
+int mgx_bgzf_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* A batch owns a pinned input buffer the caller fills (uncompressed bytes of consecutive blocks and their
  * n_blocks + 1 offsets), device memory, and a pinned output buffer.  Several batches may be in flight on
@@ -66,6 +71,8 @@ typedef struct mgx_bgzf_store mgx_bgzf_store_t;
 typedef int (*mgx_bgzf_sink_t)(void* user, const uint8_t* blocks, uint64_t n_bytes, uint32_t n_blocks, const uint64_t* block_offsets);
 int mgx_bgzf_store_create(mgx_bgzf_t* ctx, mgx_bgzf_store_t** out);
 void mgx_bgzf_store_destroy(mgx_bgzf_store_t* st);
+/* Optional: allocate HBM for about `bytes` of records now (at most one 256 MB piece) instead of inside the first put. */
+int mgx_bgzf_store_reserve(mgx_bgzf_store_t* st, uint64_t bytes);
 int mgx_bgzf_store_put(mgx_bgzf_store_t* st, const uint8_t* bytes, uint64_t n_bytes, uint64_t* device_address);
 /* order[q] = index (into addr / len / dup) of the q-th record of the output; addr[i] = device address of record i
  * (put()'s address plus the record's offset in that call's bytes), len[i] its length */

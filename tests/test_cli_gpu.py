@@ -328,3 +328,41 @@ def test_cli_on_the_sam_files_the_reference_holds(tmp_path, sd_oracle):
                 assert len(a["linear"]) == len(b["linear"]), ref                        # the same 16 kbp windows are covered
                 if 37450 in a["bins"] and 37450 in b["bins"]:
                     assert a["bins"][37450][1] == b["bins"][37450][1], ref              # mapped / unmapped record counts
+
+
+@pytest.mark.gpu
+def test_cli_falls_back_to_host_memory_when_the_device_cannot_hold_the_records(tmp_path, synth):
+    """-z device needs every BAM byte in HBM; when the estimate exceeds the free device memory the tool says so up
+    front and keeps the bytes in host memory (-z pinned) instead of failing in the middle of the ingest."""
+    raw = synth.gen_sortdedup_raw(3000, 91, n_contigs=3, contig_len=200000, dup_rate=0.2)
+    sam = str(tmp_path / "in.sam")
+    make_sam(raw, sam)
+    outs = []
+    for env_free in (None, "1000000"):
+        bam = str(tmp_path / f"o{len(outs)}.bam")
+        env = dict(os.environ)
+        if env_free:
+            env["MGX_CLI_DEVICE_FREE"] = env_free
+        res = subprocess.run([build_cli(), "-I", sam, "-O", bam, "-t", "4"], capture_output=True, text=True, env=env)
+        assert res.returncode == 0, res.stderr
+        assert ("keeping the BAM bytes in host memory" in res.stderr) == bool(env_free)
+        outs.append(gzip.decompress(open(bam, "rb").read()))
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_record_store_takes_an_empty_put(pkg):
+    """put(b"") as the first call used to touch an empty chunk list"""
+    import ctypes as C
+    comp = pkg.BgzfCompressor(0)
+    st = C.c_void_p()
+    assert comp.lib.mgx_bgzf_store_create(comp.h, C.byref(st)) == 0
+    addr = C.c_uint64(123)
+    assert comp.lib.mgx_bgzf_store_put(st, None, C.c_uint64(0), C.byref(addr)) == 0 and addr.value == 0
+    assert comp.lib.mgx_bgzf_store_reserve(st, C.c_uint64(1 << 20)) == 0
+    data = np.arange(1000, dtype=np.uint8)
+    assert comp.lib.mgx_bgzf_store_put(st, data.ctypes.data_as(C.c_void_p), C.c_uint64(1000), C.byref(addr)) == 0 and addr.value != 0
+    fr, tot = C.c_uint64(), C.c_uint64()
+    assert comp.lib.mgx_bgzf_device_memory(0, C.byref(fr), C.byref(tot)) == 0 and 0 < fr.value <= tot.value
+    comp.lib.mgx_bgzf_store_destroy(st)
+    comp.close()
