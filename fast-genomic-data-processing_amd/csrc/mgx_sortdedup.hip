@@ -345,6 +345,25 @@ __global__ __launch_bounds__(256) void k_radix_hist(const u64* __restrict__ keys
     hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];     // tile-major: coalesced
 }
 
+// "Onesweep" (round 3): the per-pass tile histograms and their three scan kernels are gone.  ONE pass over
+// a sort's keys counts every digit of every pass (global digit totals do not depend on the order of the keys), and each
+// scatter pass finds a tile's offsets by decoupled look-back over the tiles before it (k_radix_scatter<..., ONESWEEP>).
+constexpr int kMaxPasses = 8;
+constexpr int kTotalsBlocks = 2048;
+__global__ __launch_bounds__(256) void k_radix_totals(const u64* __restrict__ keys, u32 n, int first_shift, int n_passes, u32* __restrict__ totals) {
+    __shared__ u32 h[kMaxPasses * 256];
+    for (int i = threadIdx.x; i < n_passes * 256; i += 256) h[i] = 0;
+    __syncthreads();
+    const u64 per = ((u64)n + gridDim.x - 1) / gridDim.x;
+    const u64 lo = (u64)blockIdx.x * per, hi = min((u64)n, lo + per);
+    for (u64 i = lo + threadIdx.x; i < hi; i += 256) {
+        const u64 k = keys[i] >> first_shift;
+        for (int p = 0; p < n_passes; ++p) atomicAdd(&h[p * 256 + ((u32)(k >> (8 * p)) & 255u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_passes * 256; i += 256) if (h[i]) atomicAdd(&totals[i], h[i]);
+}
+
 // first pass of the record sort: the build kernel's half-tile histograms (kBuildBlock records each) -> tile histograms
 template <int TILE>
 __global__ __launch_bounds__(256) void k_hist_merge(const u32* __restrict__ half, u32 n_half, u32* __restrict__ hist) {
@@ -438,11 +457,32 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sm) {
 #define MGX_SORT_PREFETCH_P32 1
 #endif
 constexpr bool kPrefetchP32 = MGX_SORT_PREFETCH_P32 != 0;     // the 32-bit payload is loaded with the keys, not between two barriers
-template <bool HAS_P64, bool HAS_P32, int WAVES, bool LOW32 = false>
+// ONESWEEP: no precomputed offsets.  `goff` then holds the 256 digit totals of this pass, `sweep` points at
+// [8 tickets | pad to 64 words | n_tiles x 256 status words], zeroed before the launch:
+//   * tile assignment: workgroup b belongs to class x = b & 7 (the XCD it lands on under round-robin placement -- a matter
+//     of speed only) and takes ticket k from counter x.  Tiles go in chunks of kSweepChunk consecutive tiles, chunk c to class
+//     c & 7, so the two halves of a line that two neighbouring tiles complete still meet in one L2 (15 times out of 16), and
+//     the classes run a DIAGONAL schedule: class x starts x chunks late (its first x * kSweepChunk tickets map to no tile and
+//     exit), so the chunk before a class's current chunk -- another class's -- was started a whole chunk earlier and has
+//     published its prefixes when it is asked, and the tile before a tile inside a chunk holds the ticket just before its
+//     own.  Look-back walks stay short (a first version with all classes in step walked up to 8 chunks of counts per tile
+//     and lost 0.5 ms per 200 M-key pass);
+//   * status: two digits per 64-bit word, each half flag << 30 | count; flag 1 = the tile's own count, 2 = inclusive prefix
+//     over all tiles up to it.  A tile publishes its counts as soon as it has ranked its keys, walks back over its
+//     predecessors adding counts until it meets a prefix, publishes its own prefix and scatters.  One self-contained word per
+//     hand-off: relaxed agent-scope atomics (sc1 accesses), no fences;
+//   * every wait is bounded: a predecessor that does not show up within kSweepSpinLimit polls sets the error word, the tile
+//     carries on with clamped offsets (no out-of-range store) and the host re-runs the sort with the histogram passes.
+constexpr int kSweepChunk = 16;
+constexpr u32 kSweepHeaderWords = 64;
+constexpr u32 kSweepSpinLimit = 1u << 22;
+inline u32 sweep_grid_size(u32 n_tiles) { return (((n_tiles + kSweepChunk - 1) / kSweepChunk + 7) / 8 + 1) * 8 * kSweepChunk; }
+template <bool HAS_P64, bool HAS_P32, int WAVES, bool LOW32 = false, bool ONESWEEP = false>
 __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                               const u64* __restrict__ pin64, u64* __restrict__ pout64,
                                                               const u32* __restrict__ pin32, u32* __restrict__ pout32,
-                                                              u32 n, int shift, const u32* __restrict__ goff, u32 n_tiles, int xcd_order) {
+                                                              u32 n, int shift, const u32* __restrict__ goff, u32 n_tiles, int xcd_order,
+                                                              u32* __restrict__ sweep = nullptr, u32* __restrict__ sweep_err = nullptr) {
     constexpr int T = WAVES * 64;           // threads
     constexpr int ITEMS = kItems;           // keys per thread
     constexpr int kTile = T * ITEMS;        // keys per workgroup: 4096 with 4 wavefronts, 8192 with 8
@@ -457,14 +497,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restr
     // NEXT tile: giving each XCD a contiguous range of tiles (walked in order) lets both halves of
     // such a line meet in one L2 instead of reaching HBM as two partial writes from two L2s.
     u32 tile = blockIdx.x;
-    if (xcd_order) {
+    if constexpr (ONESWEEP) {
+        if (tid == 0) sm[0] = atomicAdd(&sweep[blockIdx.x & 7u], 1u);
+        __syncthreads();
+        const u32 x = blockIdx.x & 7u, lag = xcd_order > 1 ? x * (kSweepChunk / 8) : 0u;      // (xcd_order 2: staggered classes)
+        if (sm[0] < lag) return;                    // (uniform) class x starts x eighths of a chunk late: tickets then follow tile order
+        const u32 k = sm[0] - lag;
+        tile = ((k / kSweepChunk) * 8u + x) * kSweepChunk + k % kSweepChunk;
+        if (tile >= n_tiles) return;                // the grid is rounded up to whole rounds of chunks
+    } else if (xcd_order) {
         const u32 q = n_tiles >> 3, r = n_tiles & 7u, x = blockIdx.x & 7u;
         tile = x * q + min(x, r) + (blockIdx.x >> 3);
     }
     const u32 tile0 = tile * kTile;
     const u32 tile_n = min((u32)kTile, n - tile0);
     for (int i = tid; i < WAVES * 256; i += T) (&wcnt[0][0])[i] = 0;
-    const u32 my_goff = tid < 256 ? goff[(size_t)tile * 256 + tid] : 0u;
+    u32 my_goff = 0;
+    if constexpr (!ONESWEEP) my_goff = tid < 256 ? goff[(size_t)tile * 256 + tid] : 0u;
     __syncthreads();
 
     // phase 1: stable rank of every key inside its wavefront's slice
@@ -525,6 +574,53 @@ __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restr
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) { c[w] = wcnt[w][tid]; tot += c[w]; }
         }
+        if constexpr (ONESWEEP) {
+            // two digits per 64-bit status word: the even thread of a pair speaks for both
+            u64* const status = reinterpret_cast<u64*>(sweep + kSweepHeaderWords);
+            const u32 tot_hi = __shfl_down(tot, 1, 64);
+            u32 before = 0, before_hi = 0;                       // keys with this digit in the tiles before this one
+            if (tid < 256 && !(tid & 1)) {
+                u64* const mine = status + (size_t)tile * 128 + (tid >> 1);
+                const u64 counts = (u64)tot | (u64)tot_hi << 32;
+                constexpr u64 kAgg = 0x4000000040000000ull, kPre = 0x8000000080000000ull, kVal = 0x3FFFFFFF3FFFFFFFull;
+                if (tile == 0) __hip_atomic_store(mine, kPre | counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else {
+                    __hip_atomic_store(mine, kAgg | counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64* p = mine - 128;
+                    u32 spins = 0;
+                    u64 acc = 0;                                 // both halves at once: the counts stay below 2^30, no carry crosses
+                    // four predecessors per round trip (the walk is a chain of dependent loads otherwise); tiles below 0 do not
+                    // exist: tile 0 always carries a prefix, so the walk ends there at the latest
+                    u32 back = tile;                             // predecessors left
+                    bool done = false;
+                    while (!done) {
+                        u64 w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w[q] = (u32)q < back ? __hip_atomic_load(p - 128 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (done) break;
+                            u64 v = w[q];
+                            while ((v & (kAgg | kPre)) == 0) {   // not published yet
+                                if (++spins > kSweepSpinLimit) { atomicOr(sweep_err, 1u); v = kPre; break; }
+                                __builtin_amdgcn_s_sleep(1);
+                                v = __hip_atomic_load(p - 128 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            acc += v & kVal;
+                            if (v & kPre) done = true;
+                        }
+                        p -= 512; back = back > 4 ? back - 4 : 0;
+                    }
+                    before = (u32)acc & 0x3FFFFFFFu; before_hi = (u32)(acc >> 32) & 0x3FFFFFFFu;
+                    __hip_atomic_store(mine, kPre | ((acc + counts) & kVal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const u32 from_even = __shfl_up(before_hi, 1, 64);
+            if (tid & 1) before = from_even;
+            const u32 dbase = block_excl_scan<WAVES>(tid < 256 ? goff[tid] : 0u, sm);     // where the digit starts in the output
+            my_goff = dbase + before;
+            if (my_goff > n) my_goff = n;                        // only after a timed-out wait: keep every store in range
+        }
         const u32 tb = block_excl_scan<WAVES>(tot, sm);          // threads >= 256 contribute 0 after all digits
         if (tid < 256) {
             u32 run = tb;
@@ -553,6 +649,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_radix_scatter(const u64* __restr
             const u64 kk = sbuf[i];
             const u32 d = ((hi_word ? (u32)(kk >> 32) : (u32)kk) >> sh) & 255u;
             gpos[k] = gdelta[d] + i;
+            if constexpr (ONESWEEP) { if (gpos[k] >= n) gpos[k] = n - 1; }      // unreachable unless a look-back wait timed out
             if constexpr (LOW32) pout32[gpos[k]] = (u32)kk;
             else kout[gpos[k]] = kk;
         }
@@ -1079,7 +1176,9 @@ struct mgx_sortdedup {
     u64* d_nk[2] = {nullptr, nullptr}; u32* d_nrec[2] = {nullptr, nullptr};     // near double pairs
     // three independent sorts run concurrently (main: far pairs + singles, side[0]: near pairs,
     // side[1]: records), each with its own histogram / scan / long-run scratch
-    struct Scratch { u32 *hist = nullptr, *chunk = nullptr, *longl = nullptr, *multi = nullptr; } scr[3];
+    struct Scratch { u32 *hist = nullptr, *chunk = nullptr, *longl = nullptr, *multi = nullptr, *totals = nullptr; } scr[3];
+    bool onesweep_failed = false;          // a look-back wait timed out once: this context keeps to the histogram passes
+    bool onesweep = false;                 // decoupled look-back scatters (k_radix_scatter<..., ONESWEEP>); off after a timed-out wait or MGX_SORTDEDUP_ONESWEEP=0
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_ind = nullptr, ev_side[2] = {nullptr, nullptr};
     u32* d_indicator = nullptr; uint64_t indicator_bits = 0; size_t indicator_cap_words = 0;
@@ -1120,7 +1219,7 @@ void free_buffers(mgx_sortdedup* c) {
         c->d_ckey[i] = c->d_k1[i] = c->d_k2[i] = c->d_sk1[i] = nullptr;
         c->d_cval[i] = c->d_prec[i] = c->d_srec[i] = nullptr;
     }
-    for (auto& q : c->scr) { (void)hipFree(q.hist); (void)hipFree(q.chunk); (void)hipFree(q.longl); (void)hipFree(q.multi); q.hist = q.chunk = q.longl = q.multi = nullptr; }
+    for (auto& q : c->scr) { (void)hipFree(q.hist); (void)hipFree(q.chunk); (void)hipFree(q.longl); (void)hipFree(q.multi); (void)hipFree(q.totals); q.hist = q.chunk = q.longl = q.multi = q.totals = nullptr; }
     (void)hipFree(c->d_dup); c->d_dup = nullptr;
     (void)hipFree(c->d_half_hist); c->d_half_hist = nullptr;
     c->cap = 0;
@@ -1145,7 +1244,8 @@ int ensure_capacity(mgx_sortdedup* c, size_t n) {
         rc |= dalloc(&c->d_nk[i], half); rc |= dalloc(&c->d_nrec[i], half);
     }
     for (auto& q : c->scr) {
-        rc |= dalloc(&q.hist, n_tiles * 256);
+        rc |= dalloc(&q.hist, n_tiles * 256 + kSweepHeaderWords);      // tile histograms / offsets, or the look-back status words
+        rc |= dalloc(&q.totals, kMaxPasses * 256 + 64);                // digit totals of every pass of a sort + the error word
         rc |= dalloc(&q.chunk, ((n_tiles + kChunkTiles - 1) / kChunkTiles + 1) * 256);
         rc |= dalloc(&q.longl, n / kWalkCap + 16);
         rc |= dalloc(&q.multi, n / 2 + 16);          // heads of runs with >= 2 entries
@@ -1167,33 +1267,59 @@ int radix_sort_w(mgx_sortdedup* c, hipStream_t s, const mgx_sortdedup::Scratch& 
     if (n == 0) return 0;
     const u32 n_tiles = (n + TILE - 1) / TILE;
     const u32 n_chunks = (n_tiles + kChunkTiles - 1) / kChunkTiles;
+    const int n_passes = (bits + 7) / 8;
+    const bool sweep = c->onesweep && n < (1u << 30) && n_passes <= kMaxPasses;
+    u32* const sweep_err = q.totals + kMaxPasses * 256;
+    const u32 sweep_grid = sweep_grid_size(n_tiles);
+    const char* env_lag = getenv("MGX_SORTDEDUP_SWEEP_LAG");
+    const bool sweep_lag = env_lag ? atoi(env_lag) != 0 : false;
+    if (sweep) {
+        // every digit of every pass counted in ONE read of the keys
+        HIP_TRY(hipMemsetAsync(q.totals, 0, kMaxPasses * 256 * sizeof(u32), s));
+        hipLaunchKernelGGL(k_radix_totals, dim3(std::min<u32>(kTotalsBlocks, n_tiles)), dim3(256), 0, s, key[*cur], n, first_shift, n_passes, q.totals);
+        c->stats.n_key_hist_launches++;
+    }
     for (int shift = first_shift; shift < first_shift + bits; shift += 8) {
         const int in = *cur, out = in ^ 1;
-        if (first_half_hist && shift == first_shift)
-            hipLaunchKernelGGL(k_hist_merge<TILE>, dim3(n_tiles), dim3(256), 0, s, first_half_hist, (n + kBuildBlock - 1) / kBuildBlock, q.hist);
-        else
-            hipLaunchKernelGGL(k_radix_hist<TILE>, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, q.hist);
-        hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
-        hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, s, q.chunk, n_chunks);
-        hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
+        const u32* goff = q.hist;
+        u32 grid = n_tiles;
+        if (sweep) {
+            HIP_TRY(hipMemsetAsync(q.hist, 0, ((size_t)n_tiles * 256 + kSweepHeaderWords) * sizeof(u32), s));      // tickets + status words
+            goff = q.totals + (size_t)((shift - first_shift) / 8) * 256;
+            grid = sweep_grid;
+        } else {
+            if (first_half_hist && shift == first_shift)
+                hipLaunchKernelGGL(k_hist_merge<TILE>, dim3(n_tiles), dim3(256), 0, s, first_half_hist, (n + kBuildBlock - 1) / kBuildBlock, q.hist);
+            else {
+                hipLaunchKernelGGL(k_radix_hist<TILE>, dim3(n_tiles), dim3(256), 0, s, key[in], n, shift, q.hist);
+                c->stats.n_key_hist_launches++;
+            }
+            hipLaunchKernelGGL(k_radix_chunk_sums, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
+            hipLaunchKernelGGL(k_radix_scan_chunks, dim3(1), dim3(256), 0, s, q.chunk, n_chunks);
+            hipLaunchKernelGGL(k_radix_apply, dim3(n_chunks), dim3(256), 0, s, q.hist, n_tiles, q.chunk);
+        }
         const bool timing = c->ev_used + 2 <= c->ev_scatter.size();
         if (timing) HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used], s));
+        // the q.hist buffer holds the tile offsets (histogram passes) or the tickets + status words (look-back)
+#define MGX_SCATTER(P64, P32, LOW, K_IN, K_OUT, P64_IN, P64_OUT, P32_IN, P32_OUT)                                                                      \
+        do {                                                                                                                                           \
+            if (sweep) hipLaunchKernelGGL((k_radix_scatter<P64, P32, WAVES, LOW, true>), dim3(grid), dim3(WAVES * 64), 0, s, K_IN, K_OUT, P64_IN, P64_OUT, \
+                                          P32_IN, P32_OUT, n, shift, goff, n_tiles, sweep_lag ? 2 : 1, q.hist, sweep_err);                                     \
+            else hipLaunchKernelGGL((k_radix_scatter<P64, P32, WAVES, LOW, false>), dim3(grid), dim3(WAVES * 64), 0, s, K_IN, K_OUT, P64_IN, P64_OUT,      \
+                                    P32_IN, P32_OUT, n, shift, goff, n_tiles, c->xcd_order, (u32*)nullptr, (u32*)nullptr);                               \
+        } while (0)
         if (p64 && !p32)
-            hipLaunchKernelGGL((k_radix_scatter<true, false, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], p64[in], p64[out],
-                               (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist, n_tiles, c->xcd_order);
+            MGX_SCATTER(true, false, false, key[in], key[out], p64[in], p64[out], (const u32*)nullptr, (u32*)nullptr);
         else if (p64)
-            hipLaunchKernelGGL((k_radix_scatter<true, true, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], p64[in], p64[out],
-                               p32[in], p32[out], n, shift, q.hist, n_tiles, c->xcd_order);
+            MGX_SCATTER(true, true, false, key[in], key[out], p64[in], p64[out], p32[in], p32[out]);
         else if (p32)
-            hipLaunchKernelGGL((k_radix_scatter<false, true, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], (const u64*)nullptr,
-                               (u64*)nullptr, p32[in], p32[out], n, shift, q.hist, n_tiles, c->xcd_order);
+            MGX_SCATTER(false, true, false, key[in], key[out], (const u64*)nullptr, (u64*)nullptr, p32[in], p32[out]);
         else if (low32_out && shift + 8 >= first_shift + bits) {
-            hipLaunchKernelGGL((k_radix_scatter<false, false, WAVES, true>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], (const u64*)nullptr,
-                               (u64*)nullptr, (const u32*)nullptr, low32_out, n, shift, q.hist, n_tiles, c->xcd_order);
+            MGX_SCATTER(false, false, true, key[in], key[out], (const u64*)nullptr, (u64*)nullptr, (const u32*)nullptr, low32_out);
             if (low32_done) *low32_done = true;
         } else
-            hipLaunchKernelGGL((k_radix_scatter<false, false, WAVES>), dim3(n_tiles), dim3(WAVES * 64), 0, s, key[in], key[out], (const u64*)nullptr,
-                               (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, n, shift, q.hist, n_tiles, c->xcd_order);
+            MGX_SCATTER(false, false, false, key[in], key[out], (const u64*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr);
+#undef MGX_SCATTER
         if (timing) { HIP_TRY(hipEventRecord(c->ev_scatter[c->ev_used + 1], s)); c->ev_used += 2; }
         c->scatter_bytes += (uint64_t)n * 2 * (8 + (p32 ? 4 : 0) + (p64 ? 8 : 0));
         if (low32_done && *low32_done) c->scatter_bytes -= (uint64_t)n * 4;
@@ -1647,6 +1773,10 @@ int mgx_sortdedup_run(mgx_sortdedup_t* c) {
     // other sorts' bandwidth-bound scatters.  In-process A/B on one device at 200 M records
     // (tools/dev_sort_ab.py): 18.0 ms against 19.4 ms on a single stream (MGX_SORTDEDUP_STREAMS=1).
     if (const char* e = getenv("MGX_SORTDEDUP_XCD_ORDER")) c->xcd_order = atoi(e) != 0;
+    // the look-back scatters are OPT-IN: bit-identical, but measured slower than histogram + scan + scatter on this part
+    // (record sort at 200 M keys: 1.20-1.32 ms per pass against 0.36 + 0.06 + 0.68; DESIGN.md 4.2, profiles/r03_sort_onesweep_ab.txt)
+    { const char* e = getenv("MGX_SORTDEDUP_ONESWEEP"); c->onesweep = !c->onesweep_failed && (e ? atoi(e) != 0 : false); }
+    for (auto& q : c->scr) if (q.totals) HIP_TRY(hipMemsetAsync(q.totals + kMaxPasses * 256, 0, 64 * sizeof(u32), s));      // the look-back error words
     { const char* e = getenv("MGX_SORTDEDUP_WIDE_TILES"); c->wide_tiles = e ? (atoi(e) != 0) : -1; }
     if (const char* e = getenv("MGX_SORTDEDUP_NEAR_EXACT")) { if (atoi(e) != 0) c->near_by_position = false; }
     const char* env_streams = getenv("MGX_SORTDEDUP_STREAMS");
@@ -1771,6 +1901,18 @@ static int finish_run(mgx_sortdedup_t* c) {
     if (c->finished) return 0;
     HIP_TRY(hipStreamSynchronize(c->compute));
     HIP_TRY(hipMemcpy(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost));
+    u32 sweep_err = 0;
+    for (auto& q : c->scr) if (q.totals) { u32 e = 0; HIP_TRY(hipMemcpy(&e, q.totals + kMaxPasses * 256, sizeof e, hipMemcpyDeviceToHost)); sweep_err |= e; }
+    if (sweep_err) {
+        // a look-back wait ran into its bound (never seen; the protocol's progress argument assumes in-order dispatch, which
+        // HIP does not promise): the results of that run are void, run again with the histogram passes and keep to them
+        fprintf(stderr, "mgx_sortdedup: a look-back wait timed out; re-running with histogram passes\n");
+        c->onesweep_failed = true;
+        const int rc = mgx_sortdedup_run(c);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->compute));
+        HIP_TRY(hipMemcpy(&c->sc, c->d_sc, sizeof(Scalars), hipMemcpyDeviceToHost));
+    }
     if (c->sc.huge_runs && c->near_by_position) {
         c->near_by_position = false;
         const int rc = mgx_sortdedup_run(c);

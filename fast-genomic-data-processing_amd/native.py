@@ -127,6 +127,7 @@ class SortDedupStats(C.Structure):
         ("n_radix_passes", C.c_uint32), ("ms_total", C.c_float), ("ms_radix_scatter", C.c_float),
         ("radix_scatter_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
         ("ms_scatter_records", C.c_float), ("n_scatter_records", C.c_uint32), ("scatter_records_bytes", C.c_uint64),
+        ("n_key_hist_launches", C.c_uint32), ("pad_", C.c_uint32),
     ]
 
 

@@ -78,6 +78,9 @@ typedef struct mgx_sortdedup_stats {
     float ms_scatter_records;       /* sum of their durations */
     uint32_t n_scatter_records;     /* how many launches */
     uint64_t scatter_records_bytes; /* algorithmic bytes they moved (read + write) */
+    uint32_t n_key_hist_launches;   /* histogram passes of the last run that re-read the keys (k_radix_hist); the others read
+                                     * the one-byte digits the previous scatter left (k_radix_hist_bytes) or come from the build kernel */
+    uint32_t pad_;
 } mgx_sortdedup_stats_t;
 
 /* Host side (B3-B7): pair records by adjacent equal qname exactly as BamParser does, derive the

@@ -238,3 +238,30 @@ def test_streamed_upload_equals_one_shot(pkg, sd_engine, synth, monkeypatch):
     with pytest.raises(pkg.MgxError):
         sd_engine.lib.mgx_sortdedup_upload_begin(sd_engine.ctx, L, 10)
         pkg.native.check(sd_engine.lib.mgx_sortdedup_upload_end(sd_engine.ctx, 5))
+
+
+def test_lookback_scatters_give_the_same_order_and_flags(pkg, sd_oracle, synth, monkeypatch):
+    """Round 3: MGX_SORTDEDUP_ONESWEEP=1 replaces the per-pass histogram + scan kernels by one count of
+    all digits and decoupled look-back inside the scatter (opt-in: measured slower).  Same order, same flags,
+    with the classes in step and staggered, on inputs with every kind of pair."""
+    recs, L = synth.gen_sortdedup_packed_fast(3_000_000, 0x5EED0004)
+    want_order, want_dup, _ = sd_oracle.run(L, recs)
+    raw = synth.gen_sortdedup_raw(20000, 77, n_contigs=3, contig_len=40_000, dup_rate=0.4, cross_contig_rate=0.2)
+    recs2, idx2, L2 = pkg.sortdedup.pack(raw)
+    want2 = sd_oracle.run(L2, recs2)
+    for lag in ("0", "1"):
+        monkeypatch.setenv("MGX_SORTDEDUP_ONESWEEP", "1")
+        monkeypatch.setenv("MGX_SORTDEDUP_SWEEP_LAG", lag)
+        eng = pkg.SortDedupEngine(0)
+        order, dup = eng.sort_mark(L, recs)
+        st = eng.stats()
+        assert np.array_equal(order, want_order) and np.array_equal(dup, want_dup)
+        assert st["n_key_hist_launches"] <= 4          # one count of all digits per sort, no per-pass histogram of the keys
+        order2, dup2 = eng.sort_mark(L2, recs2)
+        assert np.array_equal(order2, want2[0]) and np.array_equal(dup2, want2[1])
+        eng.close()
+    monkeypatch.delenv("MGX_SORTDEDUP_ONESWEEP")
+    eng = pkg.SortDedupEngine(0)
+    eng.sort_mark(L, recs)
+    assert eng.stats()["n_key_hist_launches"] >= 8     # the default: a histogram pass per radix pass (the first from the build kernel)
+    eng.close()

@@ -12,7 +12,7 @@ names = [k for k, _ in knobs]
 variants = {}
 for combo in itertools.product(*[v.split(",") for _, v in knobs]):
     variants[" ".join(f"{k.replace('MGX_SORTDEDUP_', '')}={v}" for k, v in zip(names, combo))] = dict(zip(names, combo))
-recs, L = synth.gen_sortdedup_packed(n, 0x5EED0004)
+recs, L = synth.gen_sortdedup_packed_fast(n, 0x5EED0004, threads=16)
 eng = pkg.SortDedupEngine(0); eng.upload(L, recs)
 res = {k: [] for k in variants}; rs = {k: [] for k in variants}; sc = {k: [] for k in variants}
 ref = None
