@@ -54,8 +54,9 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-constexpr u32 kWin = 960;                       // positions per match window: 15 wavefronts extend matches, the 16th feeds them
-constexpr u32 kGrp = 8;                         // match windows between two workgroup barriers
+constexpr u32 kWin = 896;                       // positions per match window: 14 wavefronts extend matches, the 15th parses the previous group, the 16th looks up hash candidates
+constexpr u32 kParse0 = kWin, kProd0 = kWin + 64; // first thread of the parsing and of the candidate-producing wavefront
+constexpr u32 kGrp = 4;                         // match windows per GROUP: 3840 positions = 60 chunks of 64 are matched, parsed and turned into tokens before the next
 constexpr int kNT = 1024;                      // threads per workgroup = positions per match window (16 wavefronts: one block per CU, LDS-bound)
 constexpr int kHashBits = 12;
 constexpr u32 kMaxIn = MGX_BGZF_MAX_BLOCK_IN;
@@ -65,9 +66,11 @@ constexpr u32 kPad = 320;                      // zero bytes after the input in 
 constexpr u32 kCrcPoly = 0xEDB88320u;
 constexpr int kNumLL = 286, kNumD = 30, kNumCL = 19;
 constexpr int kAhead = 4;                      // windows whose tokens are fetched ahead of their use (one memory round trip per 16)
-constexpr u32 kScratchPerWg = 2u * (65536u + kAhead * 1024u);     // the match table by position, then the tokens, densely     // u32 per workgroup: decided matches, then packed tokens, by position
+constexpr u32 kScratchPerWg = 65536u + kAhead * 1024u;            // u32 per workgroup: the block's packed tokens, densely (the only per-block state that leaves the LDS)
+constexpr u32 kGrpPos = kGrp * kWin, kGrpChunks = kGrpPos / 64;
+static_assert(kGrpPos % 64 == 0, "a group is a whole number of 64-position chunks");
 
-enum { V_OVER = 0, V_NUSED, V_K, V_CRCLAST, V_NTOK, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_N };
+enum { V_OVER = 0, V_NUSED, V_K, V_CRCLAST, V_NTOK, V_NLIT, V_NDIST, V_NCLSYM, V_HDRBITS, V_STORED, V_CRC, V_CARRY, V_N };
 
 struct __attribute__((aligned(16))) Lds {
     u32 buf[(0x10000 + 512) / 4];              // the block's bytes (at the source's alignment), later the output words
@@ -87,9 +90,10 @@ struct __attribute__((aligned(16))) Lds {
     u32 bl_count[16], next_code[16];
     u32 wsum[kNT / 64];
     u64 smask[6];                              // header: which of the (up to 316) code lengths start a run
-    u16 cand[2][kGrp * kWin];                          // hash candidates (position + 1) of the current and the next window
-    u32 cend[kNT];                             // parse: where chunk t's last token ends
-    u64 mask[kNT];                             // parse: the positions of chunk t that start a token
+    u16 cand[2][kGrp * kWin];                          // hash candidates (position + 1) of the current and the next group
+    alignas(16) u32 gm[2][kGrp * kWin];                // the decided matches of the group being matched and of the one before, len << 16 | dist (0: literal)
+    u32 cend[64];                              // parse: the index of the first token of chunk l of the group
+    u64 mask[64];                              // parse: the positions of chunk l of the group that start a token
     u32 fw[288];                               // huff_build's working copy of the counts
     u8 bcost[256];                             // estimated cost of a literal byte in 1/16 bit, from the block's byte histogram
     u32 hdr[192];                              // the dynamic block header, as bits
@@ -103,7 +107,7 @@ struct DeflateArgs {
     u32 n_blocks;
     u8* slots;             // [n_blocks][kSlot]
     u32* sizes;            // [n_blocks] bytes of the finished block
-    u32* scratch;          // [gridDim.x][65536]: match table, then the tokens
+    u32* scratch;          // [gridDim.x][kScratchPerWg]: the block's tokens
     u32* n_stored;         // counter
     u32 lazy;
     u32 cost_base, cost_rle;    // estimated bits of a match's length + distance codes (distance 1: cost_rle); 0 = take every match
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     Lds& L = *reinterpret_cast<Lds*>(smem);
     const u32 tid = threadIdx.x;
-    u32* const mat = a.scratch + (size_t)blockIdx.x * kScratchPerWg;
+    u32* const tokd = a.scratch + (size_t)blockIdx.x * kScratchPerWg;
 
     if (tid < 256) {
         u32 c = tid;
@@ -408,7 +412,8 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
         // ---- 1. match search.  Wavefront 0 walks the hash table for the NEXT window, 64 positions per step: the LDS
         //         executes a wavefront's instructions in order, so a step's lookups see every earlier step's entries and
         //         none of its own -- candidates are blind to the last < 64 bytes only, and the outcome is deterministic.
-        const u32 plane = tid - kWin;                    // the producer's lane (wavefront 15)
+        if (tid == 0) { L.vars[V_NTOK] = 0; L.vars[V_CARRY] = 0; }
+        const u32 plane = tid - kProd0;                  // the producer's lane (wavefront 15)
         auto produce = [&](u32 base, u16* cb) {
             // three passes so that the LDS sees the 15 lookup / insert pairs back to back (its in-order execution is what
             // orders them), instead of a wait for every lookup's result before the next pair is issued
@@ -425,17 +430,119 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
                 c[k] = 0;
                 if (h[k] != 0xFFFFFFFFu) { c[k] = L.head[h[k]]; atomicMax(&L.head[h[k]], p + 1); }
             }
+            // (two wavefronts walking the table, each owning the hash values of one parity, give the same candidates but were
+            // measured slower: 545 k against 409 k cycles per block for the walk -- it is bound by LDS instructions, not lanes)
 #pragma unroll
             for (int k = 0; k < kSteps; ++k) cb[k * 64 + (int)plane] = (u16)c[k];
         };
         __syncthreads();
         // kGrp windows per barrier: a wavefront that meets long matches in one window catches up in the next ones
-        if (tid >= kWin)
+        if (tid >= kProd0)
             for (u32 g = 0; g < kGrp; ++g) if (g * kWin < n) produce(g * kWin, L.cand[0] + g * kWin);
         __syncthreads();
-        for (u32 grp = 0, base0 = 0; base0 < n; ++grp, base0 += kGrp * kWin) {
-          if (tid >= kWin) {                                // the last wavefront only looks candidates up, one group of windows ahead
+        // Software pipeline over groups of kGrp windows (3840 positions = 60 chunks of 64), two workgroup barriers per group:
+        //   phase A   wavefronts 0..14 decide the matches of group g (into gm[g & 1]) while wavefront 15 PARSES group g - 1
+        //             (which positions start a token: a chain, see parse_group) and then looks up the hash candidates of
+        //             group g + 1;
+        //   phase B   every wavefront turns group g - 1's token starts into packed tokens (symbol counts in LDS, the tokens
+        //             themselves densely to global memory -- the only per-position state that leaves the LDS; round 2 kept a
+        //             256 KB match table per block in global scratch, written once and read twice: 16 x the algorithmic bytes).
+        auto parse_group = [&](u32 gbase, const u32* gmv) {       // wavefront 14 only: lane l owns chunk l of the group
+            const u32 l = tid - kParse0;
+            const u32 glo = gbase + l * 64u;
+            const u32 gcl = (l < kGrpChunks && glo < n) ? min(64u, n - glo) : 0u;
+            u32 m2[32];                                      // the chunk's 64 token lengths (0 = literal), two per register
+            if (l < kGrpChunks) {
+                const uint4* v = reinterpret_cast<const uint4*>(gmv + l * 64u);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint4 x = v[q];
+                    m2[2 * q] = (x.x >> 16) | (x.y & 0xffff0000u);
+                    m2[2 * q + 1] = (x.z >> 16) | (x.w & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) m2[q] = 0;
+            }
+#define MGX_LEN_AT(i) (((i) & 1) ? m2[(i) >> 1] >> 16 : m2[(i) >> 1] & 0xffffu)
+            // The token at a position is fixed by the match phase; which positions START a token is the chain
+            // carry -> carry + len -> ...  A lane first walks its chunk from the chunk's first position (in registers, 64
+            // predicated steps), then learns where the previous chunk's last token really ends (lane 0: where the previous
+            // group's did) and only re-walks from there UNTIL THE NEW CHAIN MEETS THE OLD ONE -- two chains through the same
+            // jump table coincide from their first common position on, a few tokens in on BAM bytes --, reading the lengths
+            // from the LDS table; repeated until no chunk's start moves.  One wavefront: lane shifts and ballots, no barrier.
+            u64 mask = 0;                                    // token starts of the chunk, from cur_start
+            u32 my_end = glo;                                // where the chunk's last token ends (absolute; may pass the chunk)
+            {
+                u32 next = 0;
+#pragma unroll
+                for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < gcl) { mask |= 1ull << i; const u32 ln = MGX_LEN_AT(i); next += ln ? ln : 1u; }
+                if (gcl) my_end = glo + next;
+            }
+#undef MGX_LEN_AT
+            const u32 carry = L.vars[V_CARRY];
+            u32 cur_start = glo;
+            for (;;) {
+                const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)my_end, 0x138, 0xf, 0xf, false);      // wave_shr:1: lane l reads lane l - 1
+                const u32 prev = l == 0 ? carry : up;
+                const u32 st = max(glo, prev);
+                const bool changed = l < kGrpChunks && st != cur_start;
+                if (changed) {
+                    cur_start = st;
+                    u32 nx = st - glo;                       // chunk-relative
+                    u64 add = 0;
+                    while (nx < gcl && !((mask >> nx) & 1ull)) {
+                        add |= 1ull << nx;
+                        const u32 ln = gmv[l * 64u + nx] >> 16;
+                        nx += ln ? ln : 1u;
+                    }
+                    if (nx < gcl) mask = add | (mask & ~((1ull << nx) - 1ull));      // met the old chain: its tail (and its end) stand
+                    else { mask = add; my_end = glo + nx; }                          // left the chunk first
+                }
+                if (!__ballot(changed)) break;
+            }
+            // tokens are stored densely, in position order: a chunk's tokens start at the count of all earlier ones
+            const u32 cnt = l < kGrpChunks ? (u32)__builtin_popcountll(mask) : 0u;
+            const u32 inc = wave_scan_inclusive(cnt, OpAdd());
+            const u32 before = L.vars[V_NTOK];
+            if (l < kGrpChunks) { L.mask[l] = mask; L.cend[l] = before + inc - cnt; }            // (group-local: the next group's parse comes after this group's tokens)
+            const u32 all = wave_last(inc);
+            const u32 last_end = (u32)__builtin_amdgcn_readlane((int)my_end, (int)kGrpChunks - 1);       // ends only grow along the chunks
+            if (l == 0) { L.vars[V_NTOK] = before + all; L.vars[V_CARRY] = max(carry, last_end); }
+        };
+        auto tokens_of_group = [&](u32 gbase, const u32* gmv) {   // every thread; needs parse_group(gbase) behind a barrier
+            for (u32 q = tid; q < kGrpPos; q += kNT) {
+                const u32 p = gbase + q;
+                if (p >= n) break;
+                const u64 cmask = L.mask[q >> 6];             // (a group starts on a chunk boundary)
+                if (!((cmask >> (q & 63u)) & 1ull)) continue;
+                const u32 mm = gmv[q];
+                const u32 len = mm >> 16;
+                u32 t;
+                if (len) {
+                    u32 ls, leb, lev, ds, deb, dev;
+                    length_code(len, &ls, &leb, &lev);
+                    dist_code(mm & 0xffffu, &ds, &deb, &dev);
+                    atomicAdd(&L.f_ll[ls], 1u);
+                    atomicAdd(&L.f_d[ds], 1u);
+                    t = ls | lev << 9 | ds << 14 | dev << 19;
+                } else {
+                    t = in[p];
+                    atomicAdd(&L.f_ll[t], 1u);
+                }
+                tokd[L.cend[q >> 6] + (u32)__builtin_popcountll(cmask & ((1ull << (q & 63u)) - 1ull))] = t;
+            }
+        };
+        u32 n_groups = 0;
+        for (u32 grp = 0, base0 = 0; base0 < n; ++grp, base0 += kGrpPos) {
+          n_groups = grp + 1;
+          // ---- phase A
+          const long long ta0 = a.prof ? clock64() : 0;
+          if (tid >= kProd0) {
             for (u32 g = 0; g < kGrp; ++g) { const u32 b = base0 + (kGrp + g) * kWin; if (b < n) produce(b, L.cand[(grp + 1) & 1] + g * kWin); }
+          } else if (tid >= kParse0) {
+            if (grp) parse_group(base0 - kGrpPos, L.gm[(grp - 1) & 1]);
+            if (a.prof && tid == kParse0) atomicAdd(&a.prof[13], (unsigned long long)(clock64() - ta0));
           } else for (u32 g = 0; g < kGrp; ++g) {
             const u32 base = base0 + g * kWin;
             if (base >= n) break;
@@ -491,63 +598,27 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             // is a function of the position alone, whatever the parse does around it
             const u32 len_next = (u32)__builtin_amdgcn_update_dpp(0, (int)len, 0x130, 0xf, 0xf, false);      // wave_shl:1: lane i reads lane i + 1
             if (a.lazy && (tid & 63u) != 63u && len_next > len) len = 0;
-            mat[p] = len ? (len << 16 | dist) : 0u;
+            L.gm[grp & 1][g * kWin + tid] = len ? (len << 16 | dist) : 0u;
           }
+          if (a.prof && (tid == 0 || tid == kProd0)) atomicAdd(&a.prof[tid ? 15 : 14], (unsigned long long)(clock64() - ta0));
           __syncthreads();
+          // ---- phase B
+          const long long tb0 = a.prof ? clock64() : 0;
+          if (grp) tokens_of_group(base0 - kGrpPos, L.gm[(grp - 1) & 1]);
+          __syncthreads();
+          if (a.prof && tid == 0) atomicAdd(&a.prof[7], (unsigned long long)(clock64() - tb0));
+        }
+        if (n_groups) {                                     // the last group's parse and tokens
+            const u32 gb = (n_groups - 1) * kGrpPos;
+            if (tid >= kParse0 && tid < kProd0) parse_group(gb, L.gm[(n_groups - 1) & 1]);
+            __syncthreads();
+            tokens_of_group(gb, L.gm[(n_groups - 1) & 1]);
+            __syncthreads();
         }
         lap(1);
 
-        // ---- 2. parse.  The token at a position is fixed (above); which positions START a token is the chain
-        //         0 -> 0 + len(0) -> ...  Thread t walks the 64 positions of chunk t in registers from the position the
-        //         previous chunk's last token ends at; that end depends on where the previous chunk started, so the
-        //         walk is repeated until no chunk's start moves (two or three rounds on BAM bytes, at most one per chunk).
         const u32 lo = tid * 64u;
         const u32 cl = lo < n ? min(64u, n - lo) : 0u;
-        u32 m2[32];                                        // the chunk's 64 token lengths (0 = literal), two per register
-        {
-            const uint4* v = reinterpret_cast<const uint4*>(mat + lo);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const uint4 x = v[q];
-                m2[2 * q] = (x.x >> 16) | (x.y & 0xffff0000u);
-                m2[2 * q + 1] = (x.z >> 16) | (x.w & 0xffff0000u);
-            }
-        }
-#define MGX_LEN_AT(i) (((i) & 1) ? m2[(i) >> 1] >> 16 : m2[(i) >> 1] & 0xffffu)
-        auto walk = [&](u32 start) -> u32 {                 // chunk-relative; returns where the last token ends (may pass 64)
-            u32 next = start;
-#pragma unroll
-            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) { const u32 l = MGX_LEN_AT(i); next += l ? l : 1u; }
-            return next;
-        };
-        u32 cur_start = lo;
-        u32 my_end = cl ? lo + walk(0) : lo;
-        L.cend[tid] = my_end;
-        for (;;) {
-            __syncthreads();
-            const u32 prev = tid ? L.cend[tid - 1] : 0u;
-            const u32 st = max(lo, prev);
-            const bool changed = st != cur_start;
-            if (changed) { cur_start = st; my_end = (st >= lo + cl) ? st : lo + walk(st - lo); }
-            const int any = __syncthreads_or((int)changed);
-            if (changed) L.cend[tid] = my_end;
-            if (!any) break;
-        }
-        {
-            u64 mask = 0;
-            u32 next = cur_start - lo;
-#pragma unroll
-            for (int i = 0; i < 64; ++i) if ((u32)i == next && (u32)i < cl) { mask |= 1ull << i; const u32 l = MGX_LEN_AT(i); next += l ? l : 1u; }
-            L.mask[tid] = mask;
-            // tokens are stored densely, in position order: chunk t's tokens start at the sum of the earlier chunks' counts
-            u32 all_tokens;
-            const u32 first = block_scan(L, (u32)__builtin_popcountll(mask), &all_tokens);
-            L.cend[tid] = first;
-            if (tid == 0) L.vars[V_NTOK] = all_tokens;
-            __syncthreads();                                // the scan's partial sums are about to be reused by the CRC
-        }
-#undef MGX_LEN_AT
-        lap(13);
         // ---- 5. CRC-32 of the chunk, shifted to the end of the block
         {
             u32 c = tid == 0 ? 0xFFFFFFFFu : 0u;
@@ -575,37 +646,7 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             L.vars[V_CRC] = multmodp(L.xr[r], c) ^ L.vars[V_CRCLAST] ^ 0xFFFFFFFFu;
         }
         lap(2);
-        // ---- tokens, position-parallel: the token starting at a position in packed form, stored densely, and the symbol counts
-        u32* const tokd = mat + 65536u + kAhead * 1024u;
         const u32 n_tok = L.vars[V_NTOK];
-        const u32 n_win = (n + kNT - 1) / kNT;
-        for (u32 w0 = 0; w0 < n_win; w0 += kAhead) {
-            u32 mm[kAhead];
-#pragma unroll
-            for (int j = 0; j < kAhead; ++j) mm[j] = mat[(w0 + j) * kNT + tid];          // (in bounds: the array has 64 + kAhead windows)
-#pragma unroll
-            for (int j = 0; j < kAhead; ++j) {
-                const u32 p = (w0 + j) * kNT + tid;
-                u32 t = kTokNone;
-                const u64 cmask = p < n ? L.mask[p >> 6] : 0ull;
-                if ((cmask >> (p & 63u)) & 1ull) {
-                    const u32 len = mm[j] >> 16;
-                    if (len) {
-                        u32 ls, leb, lev, ds, deb, dev;
-                        length_code(len, &ls, &leb, &lev);
-                        dist_code(mm[j] & 0xffffu, &ds, &deb, &dev);
-                        atomicAdd(&L.f_ll[ls], 1u);
-                        atomicAdd(&L.f_d[ds], 1u);
-                        t = ls | lev << 9 | ds << 14 | dev << 19;
-                    } else {
-                        t = in[p];
-                        atomicAdd(&L.f_ll[t], 1u);
-                    }
-                }
-                if (t != kTokNone) tokd[L.cend[p >> 6] + (u32)__builtin_popcountll(cmask & ((1ull << (p & 63u)) - 1ull))] = t;
-            }
-        }
-        __syncthreads();
         lap(3);
 
         // ---- 3. codes
@@ -714,50 +755,33 @@ __global__ __launch_bounds__(kNT) void k_bgzf_deflate(DeflateArgs a) {
             for (u32 w = tid; w < nw; w += kNT) L.buf[w] = 0;
             __syncthreads();
             for (u32 w = tid; w < ((hdr_bits + 31) >> 5); w += kNT) atomicOr(&L.buf[w], L.hdr[w]);
-            // bit offset of every (window, wavefront) group of 64 positions: their totals, scanned in position order
-            const u32 lane = tid & 63u, wave = tid >> 6;
-            const u32 n_tw = (n_tok + kNT - 1) / kNT;         // windows of 1024 TOKENS from here on
-            L.cend[tid] = 0;
-            __syncthreads();
-            for (u32 w0 = 0; w0 < n_tw; w0 += kAhead) {
-                u32 t4[kAhead];
-#pragma unroll
-                for (int j = 0; j < kAhead; ++j) { const u32 i = (w0 + j) * kNT + tid; t4[j] = i < n_tok ? tokd[i] : kTokNone; }
-#pragma unroll
-                for (int j = 0; j < kAhead; ++j) {
-                    const u32 v = wave_last(wave_scan_inclusive(token_bits(L, t4[j]), OpAdd()));
-                    if (lane == 0 && w0 + j < n_tw) L.cend[(w0 + j) * (kNT / 64) + wave] = v;
-                }
-            }
-            __syncthreads();
-            u32 all_bits;
-            const u32 group_off = block_scan(L, L.cend[tid], &all_bits);
-            __syncthreads();
-            L.cend[tid] = hdr_bits + group_off;
-            __syncthreads();
-            for (u32 w0 = 0; w0 < n_tw; w0 += kAhead) {
-                u32 t4[kAhead];
-#pragma unroll
-                for (int j = 0; j < kAhead; ++j) { const u32 i = (w0 + j) * kNT + tid; t4[j] = i < n_tok ? tokd[i] : kTokNone; }
-#pragma unroll
-                for (int j = 0; j < kAhead; ++j) {
-                    const u32 t = t4[j];
-                    const u32 nb = token_bits(L, t);
-                    const u32 inc = wave_scan_inclusive(nb, OpAdd());
-                    if (nb) {
-                        BitSink s;
-                        s.start(L.buf, L.cend[(w0 + j) * (kNT / 64) + wave] + inc - nb);
-                        const u32 ls = t & 0x1FFu;
-                        s.put(L.c_ll[ls], L.l_ll[ls]);
-                        if (ls > 256) {
-                            const u32 ds = (t >> 14) & 31u, leb = length_extra_bits(ls), deb = dist_extra_bits(ds);
-                            if (leb) s.put((t >> 9) & 31u, leb);
-                            s.put(L.c_d[ds], L.l_d[ds]);
-                            if (deb) s.put(t >> 19, deb);
-                        }
-                        s.finish();
+            // The tokens are read ONCE, a window of 1024 at a time: a window's bit offsets are the bits of the earlier windows
+            // (carried in a register) plus a workgroup scan of its own tokens' sizes; the next window's tokens are already in
+            // flight during the scan.  (Round 2 read the token list twice: once for the sizes, once for the bits.)
+            const u32 n_tw = (n_tok + kNT - 1) / kNT;
+            u32 all_bits = 0;
+            u32 tnext = tid < n_tok ? tokd[tid] : kTokNone;
+            for (u32 w = 0; w < n_tw; ++w) {
+                const u32 t = tnext;
+                const u32 inext = (w + 1) * kNT + tid;
+                tnext = inext < n_tok ? tokd[inext] : kTokNone;
+                const u32 nb = token_bits(L, t);
+                u32 win_bits;
+                const u32 off = block_scan(L, nb, &win_bits);
+                if (nb) {
+                    BitSink sk;
+                    sk.start(L.buf, hdr_bits + all_bits + off);
+                    const u32 ls = t & 0x1FFu;
+                    sk.put(L.c_ll[ls], L.l_ll[ls]);
+                    if (ls > 256) {
+                        const u32 ds = (t >> 14) & 31u, leb = length_extra_bits(ls), deb = dist_extra_bits(ds);
+                        if (leb) sk.put((t >> 9) & 31u, leb);
+                        sk.put(L.c_d[ds], L.l_d[ds]);
+                        if (deb) sk.put(t >> 19, deb);
                     }
+                    sk.finish();
                 }
+                all_bits += win_bits;
             }
             const u32 carry = hdr_bits + all_bits;
             if (tid == 0) { BitSink s; s.start(L.buf, carry); s.put(L.c_ll[256], L.l_ll[256]); s.finish(); }
@@ -990,7 +1014,8 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
         if (hipMemcpy(p, c->d_prof, sizeof p, hipMemcpyDeviceToHost) == hipSuccess && c->n_blocks) {
             fprintf(stderr, "mgx_bgzf cycles per block: load %llu, match %llu, parse+crc %llu, tokens %llu, huffman %llu, header %llu, emit %llu\n", p[0] / c->n_blocks,
                     p[1] / c->n_blocks, p[2] / c->n_blocks, p[3] / c->n_blocks, p[4] / c->n_blocks, p[5] / c->n_blocks, p[6] / c->n_blocks);
-            fprintf(stderr, "   parse alone (the rest of parse+crc is the CRC): %llu\n", p[13] / c->n_blocks);
+            fprintf(stderr, "   parse of the groups on wavefront 14 (inside phase A): %llu\n", p[13] / c->n_blocks);
+            fprintf(stderr, "   inside match: phase A as wavefront 0 sees it %llu, as wavefront 15 (hash candidates) %llu; phase B (tokens) %llu\n", p[14] / c->n_blocks, p[15] / c->n_blocks, p[7] / c->n_blocks);
             fprintf(stderr, "   literal/length code: setup %llu, rank %llu, merge rounds %llu, depths %llu, codes %llu\n", p[8] / c->n_blocks, p[9] / c->n_blocks, p[10] / c->n_blocks, p[11] / c->n_blocks, p[12] / c->n_blocks);
         }
         (void)hipFree(c->d_prof);

@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d "$OUT/$c" -o bench --output-format csv -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --pairs 65536 --sort-records 0 --sw-pairs 0 --no-queue --no-ragged --no-regions --no-cpu-baseline --bgzf-mb 512 --cli-records 0 > "$OUT/$c.json" 2> "$OUT/$c.err" || echo "$c run failed"
+  rocprofv3 --pmc $c -d "$OUT/$c" -o bench --output-format csv -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --pairs 65536 --sort-records 0 --sw-pairs 0 --no-queue --no-ragged --no-regions --no-cpu-baseline --bgzf-mb 512 --cli-records 0 --no-mixed > "$OUT/$c.json" 2> "$OUT/$c.err" || echo "$c run failed"
 done
 cd "$REPO"
 python3 - "$OUT" <<'PY'
