@@ -33,6 +33,8 @@ PKG = "fast-genomic-data-processing_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+VALU_INT32_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # one int32 lane-operation per lane per clock: 78.6 T lane-op/s
+SW_INSTR_PER_CELL = 32         # k_sw_fill as compiled
 
 
 def host_cores():
@@ -236,12 +238,13 @@ def smithwaterman_leg(pkg, synth, args, rank, local_rank):
            "config": {"workload": "synthetic reads (100-151 bases) against haplotype windows (250-400 bases), STANDARD_NGS "
                                   "parameters, SOFTCLIP", "pairs": n, "cells": st["cells"]},
            "ms_fill": ms_fill, "ms_trace": ms_trace, "backtrace_bytes": st["backtrace_bytes"],
-           "roofline": {"bound": "hbm", "achieved": st["cells"] / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": st["cells"] / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+           "roofline": {"bound": "valu", "achieved": st["cells"] * SW_INSTR_PER_CELL / (ms_fill * 1e-3) / 1e12, "peak": VALU_INT32_PEAK_TOPS,
+                        "unit": "T lane-op/s", "frac": st["cells"] * SW_INSTR_PER_CELL / (ms_fill * 1e-3) / 1e12 / VALU_INT32_PEAK_TOPS, "traffic": None,
                         "kernel": "k_sw_fill<8>", "kernel_ms": ms_fill,
-                        "note": "1 algorithmic byte per cell (the back-trace byte); the fill is int32-VALU bound (about 22 "
-                                "instructions per cell, 64 % of the lanes and 76 % of the anti-diagonal steps busy at this shape), "
-                                "the trace is a latency chain"}}
+                        "hbm": {"achieved": st["cells"] / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": st["cells"] / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "1 algorithmic byte per cell (the back-trace byte)"},
+                        "note": "the fill is int32-VALU bound: 32 instructions per cell as compiled (DESIGN.md 4b) against 256 CUs x 4 SIMDs x 32 lanes x "
+                                "2.4 GHz = 78.6 T lane-op/s; 64 % of the lanes and 76 % of the anti-diagonal steps are busy at this shape; the trace is a latency chain"}}
     if not args.no_cpu_baseline:
         so = os.path.join(ROOT, "oracle", "_ref", "libref_smithwaterman.so")
         if os.path.exists(so):
@@ -308,14 +311,16 @@ def bgzf_leg(pkg, synth, args, rank, local_rank):
                       "blocks_per_batch": per, "batches": n_batches, "bytes": n_batches * per * B},
            "compressed_over_input": ratio, "pinned_to_pinned_GBps": n_batches * per * B / dt / 1e9, "blocks_stored": int(st["n_stored"]),
            "inflates_to_input": bool(ok),
-           "roofline": {"bound": "hbm", "limiter": "lds-latency", "achieved": alg / kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "lds", "achieved": alg / kernel_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / kernel_ms / 1e6 / HBM_PEAK_GBS, "traffic": measured_traffic("k_bgzf_deflate"),
                         "traffic_source": "offline rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in this run",
                         "kernel": "k_bgzf_deflate", "kernel_ms": kernel_ms,
                         "kernel_ms_source": "HIP events around the deflate + offsets + pack kernels of a batch, median over the batches",
                         "alg_bytes_per_launch": alg,
-                        "note": "entropy coding: serial dependences inside a block (hash chains, Huffman construction, bit offsets) run in "
-                                "LDS, one 64 KB block per workgroup; the HBM roof is not what binds it"}}
+                        "note": "what binds it is LDS latency on serial chains, not a byte rate: one wavefront per workgroup walks the hash table in "
+                                "order (409 k of the 880 k cycles of a block; DESIGN.md 4.6), beside it the Huffman construction and the bit offsets; one "
+                                "64 KB block per workgroup, one workgroup per CU.  No LDS roof is published for such chains, so `achieved` / `frac` are "
+                                "the algorithmic bytes (input once, compressed output once) against the HBM peak, as BASELINE.json's metric words it"}}
     if not args.no_cpu_baseline:
         sample = bytes(src[:256 * B])
         t0 = time.perf_counter()
@@ -437,7 +442,7 @@ def regions_leg(pkg, synth, local_rank, lanes):
         t0 = time.perf_counter(); eng.compute_regions(prepared=prep); ts.append(time.perf_counter() - t0)
     one = float(np.median(ts))
     want = [x.copy() for x in prep["outs"]]
-    q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
+    q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=131072)
     q.run_regions(prepared=prep)
     ts = []
     for _ in range(7):
@@ -667,7 +672,7 @@ def main():
     mixed_line = mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_over_ranks) if not args.no_mixed else None
     if rank == 0:
         if not args.no_regions:
-            line["regions"] = regions_leg(pkg, synth, local_rank, max(2, min(4, host_cores() // world)))
+            line["regions"] = regions_leg(pkg, synth, local_rank, 3)      # three lanes, 131072 test cases per batch: the best of the sweep in profiles/r03_regions_queue_sweep.txt
         if mixed_line is not None:
             line["mixed"] = mixed_line
         if sort_line is not None:
