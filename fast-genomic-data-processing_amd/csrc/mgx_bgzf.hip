@@ -831,21 +831,24 @@ __global__ __launch_bounds__(256) void k_bgzf_offsets(const u32* sizes, u32 n, u
     for (u32 i = lo; i < hi; ++i) { out_off[i] = run; run += sizes[i]; }
 }
 
-// slot -> its place in the packed output
-__global__ __launch_bounds__(256) void k_bgzf_pack(const u8* slots, const u32* sizes, const u64* out_off, u8* out) {
-    const u32 blk = blockIdx.x;
-    const u8* src = slots + (size_t)blk * kSlot + kSlotSkew;
-    u8* dst = out + out_off[blk];
-    const u32 n = sizes[blk];
-    // destination-aligned words, source read with whatever alignment it has
-    const u32 lead = min(n, (u32)((4u - ((uintptr_t)dst & 3u)) & 3u));
-    if (threadIdx.x < lead) dst[threadIdx.x] = src[threadIdx.x];
-    const u32 nw = (n - lead) >> 2;
-    u32* dw = reinterpret_cast<u32*>(dst + lead);
-    const u8* sb = src + lead;
-    for (u32 w = threadIdx.x; w < nw; w += 256) dw[w] = load32(sb + 4 * (size_t)w);
-    const u32 done = lead + 4 * nw;
-    if (threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+// slot -> its place in the packed output (pinned host memory: the stores cross PCIe).  A bounded grid of small workgroups
+// walks the blocks: a workgroup per block would fill every CU's wavefront slots with stores waiting on the link and keep the
+// next batch's 1024-thread deflate workgroups from being placed.
+__global__ __launch_bounds__(256) void k_bgzf_pack(const u8* slots, const u32* sizes, const u64* out_off, u8* out, u32 n_blocks) {
+    for (u32 blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const u8* src = slots + (size_t)blk * kSlot + kSlotSkew;
+        u8* dst = out + out_off[blk];
+        const u32 n = sizes[blk];
+        // destination-aligned words, source read with whatever alignment it has
+        const u32 lead = min(n, (u32)((4u - ((uintptr_t)dst & 3u)) & 3u));
+        if (threadIdx.x < lead) dst[threadIdx.x] = src[threadIdx.x];
+        const u32 nw = (n - lead) >> 2;
+        u32* dw = reinterpret_cast<u32*>(dst + lead);
+        const u8* sb = src + lead;
+        for (u32 w = threadIdx.x; w < nw; w += 256) dw[w] = load32(sb + 4 * (size_t)w);
+        const u32 done = lead + 4 * nw;
+        if (threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+    }
 }
 
 // ---- the record store: records resident in HBM, emitted in sorted order ------------------------------------------
@@ -919,22 +922,24 @@ struct mgx_bgzf {
     int n_cu = 0;
     hipStream_t stream = nullptr;              // all batches of a context run in order on one stream
     hipStream_t copy = nullptr;                // packed blocks travel back on a stream of their own, behind their batch's kernels only
+    hipStream_t up = nullptr;                  // ... and a batch's input travels up on a third one, under the kernels of the batch before
     std::mutex prep_mu; bool prepared = false; // the compressor's scratch and kernel attributes: set up at first use (or mgx_bgzf_prepare)
     u32* d_scratch = nullptr; u32 grid = 0;
     u32* d_n_stored = nullptr;
     unsigned long long* d_prof = nullptr;
     u32 lazy = 1, cost_base = 10, cost_rle = 6;
     u64 n_blocks = 0, bytes_in = 0, bytes_out = 0;
-    float ms_kernels = 0;
+    float ms_kernels = 0, ms_pack = 0;
 };
 
 struct mgx_bgzf_batch {
     u64 in_cap = 0; u32 max_blocks = 0;
     u8* h_in = nullptr; u64* h_off = nullptr;          // pinned, filled by the caller
     u8* h_out = nullptr; u64* h_out_off = nullptr;     // pinned, results
-    u8* d_in = nullptr; u64* d_off = nullptr; u8* d_slots = nullptr; u32* d_sizes = nullptr; u64* d_out_off = nullptr; u8* d_out = nullptr;
+    u8* d_in = nullptr; u64* d_off = nullptr; u8* d_slots = nullptr; u32* d_sizes = nullptr; u64* d_out_off = nullptr;
     u64 out_cap = 0;
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_off = nullptr, ev_out = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_p0 = nullptr, ev_out = nullptr, ev_in = nullptr;
+    u8* h_out_dev = nullptr;                          // the pinned output buffer as the device addresses it
     u32 n_blocks = 0; u64 n_in = 0;
     bool submitted = false;
 };
@@ -963,7 +968,12 @@ int mgx_bgzf_create(int device, unsigned flags, mgx_bgzf_t** out) {
     if (const char* e = getenv("MGX_BGZF_COST_RLE")) c->cost_rle = (u32)atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
-    c->grid = (u32)c->n_cu;                       // ~94 KB of LDS per workgroup: one per CU
+    HIP_TRY(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking));
+    // one workgroup per CU (157 KB of LDS, 1024 threads x 128 registers: a CU that runs one has no register left for anything
+    // else, so the pack kernel of the batch before cannot run BESIDE a deflate kernel, only between two).  Leaving 8 or 16 CUs
+    // free for it was measured: the deflate kernel then takes 9 rounds instead of 8 over a 2048-block batch (3.39 against
+    // 3.04 ms) and pinned -> pinned falls from 28.0 to 24.1 GB/s.
+    c->grid = (u32)c->n_cu;
     if (const char* e = getenv("MGX_BGZF_GRID")) { const int v = atoi(e); if (v > 0) c->grid = (u32)v; }
     // the compressor's own device state (scratch tables, counters, the kernel's LDS attribute -- which loads the code
     // object) is set up by the first batch or by mgx_bgzf_prepare: a record store needs none of it, and a tool that
@@ -1007,6 +1017,7 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
+    if (c->up) { (void)hipStreamSynchronize(c->up); (void)hipStreamDestroy(c->up); }
     (void)hipFree(c->d_scratch);
     (void)hipFree(c->d_n_stored);
     if (c->d_prof) {
@@ -1025,13 +1036,14 @@ void mgx_bgzf_destroy(mgx_bgzf_t* c) {
 
 void mgx_bgzf_batch_destroy(mgx_bgzf_t* c, mgx_bgzf_batch_t* b) {
     if (!b) return;
-    if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy); }
+    if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->up); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy); }
     (void)hipHostFree(b->h_in); (void)hipHostFree(b->h_off); (void)hipHostFree(b->h_out); (void)hipHostFree(b->h_out_off);
-    (void)hipFree(b->d_in); (void)hipFree(b->d_off); (void)hipFree(b->d_slots); (void)hipFree(b->d_sizes); (void)hipFree(b->d_out_off); (void)hipFree(b->d_out);
+    (void)hipFree(b->d_in); (void)hipFree(b->d_off); (void)hipFree(b->d_slots); (void)hipFree(b->d_sizes); (void)hipFree(b->d_out_off);
     if (b->ev_k0) (void)hipEventDestroy(b->ev_k0);
     if (b->ev_k1) (void)hipEventDestroy(b->ev_k1);
-    if (b->ev_off) (void)hipEventDestroy(b->ev_off);
+    if (b->ev_p0) (void)hipEventDestroy(b->ev_p0);
     if (b->ev_out) (void)hipEventDestroy(b->ev_out);
+    if (b->ev_in) (void)hipEventDestroy(b->ev_in);
     delete b;
 }
 
@@ -1060,10 +1072,11 @@ static int batch_create(mgx_bgzf_t* c, uint64_t in_capacity, uint32_t max_blocks
     if (hipMalloc((void**)&b->d_slots, (size_t)max_blocks * kSlot) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&b->d_sizes, (size_t)max_blocks * sizeof(u32)) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&b->d_out_off, ((size_t)max_blocks + 1) * sizeof(u64)) != hipSuccess) return fail("hipMalloc");
-    if (hipMalloc((void**)&b->d_out, b->out_cap) != hipSuccess) return fail("hipMalloc");
+    if (hipHostGetDevicePointer((void**)&b->h_out_dev, b->h_out, 0) != hipSuccess) return fail("hipHostGetDevicePointer");
     if (hipEventCreate(&b->ev_k0) != hipSuccess || hipEventCreate(&b->ev_k1) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_off, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
+        hipEventCreate(&b->ev_p0) != hipSuccess ||
+        hipEventCreate(&b->ev_out) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate");
     b->h_off[0] = 0;
     *out = b;
     return 0;
@@ -1091,19 +1104,32 @@ static int batch_submit(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, uint32_t n_blocks, b
     b->n_blocks = n_blocks; b->n_in = n_in; b->submitted = true;
     if (n_blocks == 0) { b->h_out_off[0] = 0; return 0; }
     hipStream_t s = c->stream;
-    if (!input_resident) HIP_TRY(hipMemcpyAsync(b->d_in, b->h_in, n_in, hipMemcpyHostToDevice, s));
+    if (!input_resident) {
+        // the input goes up on its own stream: on the kernel stream it would wait for the deflate kernels of the batches
+        // submitted before (d_in was last read by this batch's previous kernels, which its last wait() has seen finish)
+        HIP_TRY(hipMemcpyAsync(b->d_in, b->h_in, n_in, hipMemcpyHostToDevice, c->up));
+        HIP_TRY(hipEventRecord(b->ev_in, c->up));
+        HIP_TRY(hipStreamWaitEvent(s, b->ev_in, 0));
+    }
     HIP_TRY(hipMemcpyAsync(b->d_off, b->h_off, ((size_t)n_blocks + 1) * sizeof(u64), hipMemcpyHostToDevice, s));
     DeflateArgs a{};
     a.in = b->d_in; a.off = b->d_off; a.n_blocks = n_blocks; a.slots = b->d_slots; a.sizes = b->d_sizes;
     a.scratch = c->d_scratch; a.n_stored = c->d_n_stored; a.lazy = c->lazy; a.cost_base = c->cost_base; a.cost_rle = c->cost_rle; a.prof = c->d_prof;
     HIP_TRY(hipEventRecord(b->ev_k0, s));
     hipLaunchKernelGGL(k_bgzf_deflate, dim3(std::min(c->grid, n_blocks)), dim3(kNT), sizeof(Lds), s, a);
-    hipLaunchKernelGGL(k_bgzf_offsets, dim3(1), dim3(256), 0, s, b->d_sizes, n_blocks, b->d_out_off);
-    hipLaunchKernelGGL(k_bgzf_pack, dim3(n_blocks), dim3(256), 0, s, b->d_slots, b->d_sizes, b->d_out_off, b->d_out);
     HIP_TRY(hipEventRecord(b->ev_k1, s));
+    // The finished blocks are packed STRAIGHT INTO THE PINNED OUTPUT BUFFER by the pack kernel, on the copy stream behind this
+    // batch's deflate kernel only: no packed copy in HBM and no device-to-host copy behind it (round 2's was carried out by
+    // a blit kernel that took 4.3 ms beside the next batch's deflate kernel and slowed that one from 3.0 to 4.1 ms:
+    // 20 GB/s pinned to pinned; tools trace in profiles/r03_bgzf_pipeline_trace.txt), and the next batch's deflate kernel
+    // does not queue behind the packing.
+    HIP_TRY(hipStreamWaitEvent(c->copy, b->ev_k1, 0));
+    HIP_TRY(hipEventRecord(b->ev_p0, c->copy));
+    hipLaunchKernelGGL(k_bgzf_offsets, dim3(1), dim3(256), 0, c->copy, b->d_sizes, n_blocks, b->d_out_off);
+    hipLaunchKernelGGL(k_bgzf_pack, dim3(std::min<u32>(n_blocks, (u32)c->n_cu)), dim3(256), 0, c->copy, b->d_slots, b->d_sizes, b->d_out_off, b->h_out_dev, n_blocks);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(b->h_out_off, b->d_out_off, ((size_t)n_blocks + 1) * sizeof(u64), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(b->ev_off, s));
+    HIP_TRY(hipMemcpyAsync(b->h_out_off, b->d_out_off, ((size_t)n_blocks + 1) * sizeof(u64), hipMemcpyDeviceToHost, c->copy));
+    HIP_TRY(hipEventRecord(b->ev_out, c->copy));
     return 0;
 }
 
@@ -1114,18 +1140,12 @@ int mgx_bgzf_batch_wait(mgx_bgzf_t* c, mgx_bgzf_batch_t* b, const uint8_t** out,
     *out = b->h_out; *out_offsets = b->h_out_off;
     b->submitted = false;
     if (b->n_blocks == 0) return 0;
-    HIP_TRY(hipEventSynchronize(b->ev_off));
+    HIP_TRY(hipEventSynchronize(b->ev_out));
     const u64 total = b->h_out_off[b->n_blocks];
     if (total > b->out_cap) { set_error("internal: %llu output bytes exceed the bound %llu", (unsigned long long)total, (unsigned long long)b->out_cap); return -EIO; }
-    // the packed blocks: exactly their bytes, on the copy stream behind THIS batch's kernels only -- on the kernel stream
-    // the copy would queue behind the deflate kernels of the batches submitted since, and waiting for it would drain them
-    // (the device then idles while the caller writes this batch out)
-    HIP_TRY(hipStreamWaitEvent(c->copy, b->ev_k1, 0));
-    HIP_TRY(hipMemcpyAsync(b->h_out, b->d_out, total, hipMemcpyDeviceToHost, c->copy));
-    HIP_TRY(hipEventRecord(b->ev_out, c->copy));
-    HIP_TRY(hipEventSynchronize(b->ev_out));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, b->ev_k0, b->ev_k1) == hipSuccess) c->ms_kernels = ms;
+    float ms = 0, ms_pack = 0;
+    if (hipEventElapsedTime(&ms, b->ev_k0, b->ev_k1) == hipSuccess && hipEventElapsedTime(&ms_pack, b->ev_p0, b->ev_out) == hipSuccess)
+    { c->ms_kernels = ms; c->ms_pack = ms_pack; }     // the deflate kernel | offsets + pack (its stores cross PCIe) + offsets read-back on the copy stream
     c->n_blocks += b->n_blocks; c->bytes_in += b->n_in; c->bytes_out += total;
     return 0;
 }
@@ -1366,7 +1386,7 @@ int mgx_bgzf_stats(mgx_bgzf_t* c, mgx_bgzf_stats_t* out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     u32 ns = 0;
     if (c->d_n_stored) HIP_TRY(hipMemcpy(&ns, c->d_n_stored, sizeof ns, hipMemcpyDeviceToHost));
-    out->n_blocks = c->n_blocks; out->bytes_in = c->bytes_in; out->bytes_out = c->bytes_out; out->n_stored = ns; out->ms_kernels = c->ms_kernels;
+    out->n_blocks = c->n_blocks; out->bytes_in = c->bytes_in; out->bytes_out = c->bytes_out; out->n_stored = ns; out->ms_kernels = c->ms_kernels; out->ms_pack = c->ms_pack;
     return 0;
 }
 

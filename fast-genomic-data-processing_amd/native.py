@@ -188,7 +188,7 @@ SYMBOLS.update(SMITHWATERMAN_SYMBOLS)
 # ---- include/mgx_bgzf.h ---------------------------------------------------------------------------
 class BgzfStats(C.Structure):
     _fields_ = [("n_blocks", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64), ("n_stored", C.c_uint64),
-                ("ms_kernels", C.c_float)]
+                ("ms_kernels", C.c_float), ("ms_pack", C.c_float)]
 
 
 BGZF_SYMBOLS = {

@@ -82,7 +82,9 @@ int mgx_bgzf_store_emit(mgx_bgzf_store_t* st, uint64_t n, const uint32_t* order,
 typedef struct mgx_bgzf_stats {
     uint64_t n_blocks, bytes_in, bytes_out;   /* since create */
     uint64_t n_stored;                        /* blocks emitted as stored (incompressible) */
-    float ms_kernels;                         /* last batch waited for: deflate + pack kernels (HIP events) */
+    float ms_kernels;                         /* last batch waited for: the deflate kernel (HIP events on its stream) */
+    float ms_pack;                            /* ... and offsets + pack on the copy stream: the pack kernel stores the finished blocks
+                                               * straight into the pinned output buffer, i.e. this is the device-to-host transfer */
 } mgx_bgzf_stats_t;
 int mgx_bgzf_stats(mgx_bgzf_t* ctx, mgx_bgzf_stats_t* out);
 
