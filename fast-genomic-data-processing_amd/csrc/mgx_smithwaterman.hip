@@ -22,6 +22,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
 #include <memory>
 #include <new>
 #include <thread>
@@ -55,20 +57,38 @@ struct SwJob {
     u64 sc_off;          // score arena (int32): last_row[ncol + 1] then last_col[nrow + 1]
     u64 el_off;          // element arena (int16): 2 * (len1 + len2 + 2)
     u32 len1, len2, rpl, strategy, out_index;
-    u32 g;               // lanes per pair (32 or 64)
+    u32 g;               // bits 0-7: lanes per pair (32 or 64) | kJobTr | kJobI16 | kJobHalf
+    u64 lr_off;          // 16-bit fill: the last lane's H values per swept position (back-trace arena, bytes)
+    u64 lc_off;          // 16-bit fill: every lane's packed H values at the pair's last swept position
+    int32_t low16;       // 16-bit fill: this pair's stand-in for LOW_INIT_VALUE
+    u32 pad_;
 };
+constexpr u32 kJobTr = 0x100u;      // k_sw_fill<.., TR>: the lanes own the alternate sequence
+constexpr u32 kJobI16 = 0x200u;     // k_sw_fill16: packed 16-bit scores, two pairs per lane group, back-trace nibbles
+constexpr u32 kJobHalf = 0x400u;    // k_sw_fill16: this pair is the high half of its lane group
+constexpr u32 kNoOutput = 0xFFFFFFFFu;   // out_index of a filler job (a 16-bit class is padded to whole wavefronts)
 
 struct SwResult { int32_t score, max_i, max_j, offset, n_elems; };
+// back-trace bytes of one lane and step: RPL of them, in a slot of whole 32-bit words from three positions per lane up (a 5-, 6- or
+// 7-byte slot would be stored byte by byte)
+__host__ __device__ constexpr int bt_slot(int rpl) { return rpl <= 2 ? rpl : (rpl + 3) & ~3; }
 struct SwParams { int match, mismatch, open, extend; };
 
 // G lanes per pair (two pairs share a wavefront when G = 32), RPL rows per lane.  Back-trace byte:
 // bits 0-1 op, bit 2 INSERT_EXT, bit 3 DELETE_EXT (PairWiseSW.h:31-66).  (Storing the length of the
 // diagonal match run in the spare bits, so that the trace crosses a run in one step, was measured:
 // trace 0.58 -> 0.38 ms, fill 1.14 -> 1.42 ms per 20 000 pairs -- not kept.)
-template <int G, int RPL>
+// TR (round 3): the lanes own the ALTERNATE sequence's positions (columns j) and sweep the reference (rows i) -- the
+// transposed recurrence.  The reads realigned after PairHMM are 100-151 bases against haplotype windows of 250-400: with the
+// lanes over the reference, 64 lanes x 8 rows hold 250-400 rows (49-78 % of the row slots) and a pair takes ncol + 63 steps of
+// which ncol do work (66 %); with the lanes over the read, 32 lanes x 4-5 positions hold 100-151 (78-100 %) and a pair takes
+// nrow + 31 steps of which nrow do work (91 %), two pairs per wavefront.  Every cell computes the same values with the same tie
+// rules: E (horizontal gap) is the state carried along the sweep when the lanes own rows and the chain handed from position to
+// position when they own columns, F (vertical gap) the other way round; H still prefers the diagonal, then E, then F.
+template <int G, int RPL, bool TR>
 __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, u32 n_jobs, const u8* __restrict__ s1, const u8* __restrict__ s2,
                                                 u8* __restrict__ bt, int32_t* __restrict__ sc, u32 lds_stride, SwParams P) {
-    extern __shared__ u8 sh_all[];                    // the alternate sequences: one global load per step would
+    extern __shared__ u8 sh_all[];                    // the swept sequences: one global load per step would
     constexpr int GPW = 64 / G;                       // put ~200 serial HBM latencies on every wavefront's path
     const int grp = threadIdx.x / G, lane = threadIdx.x % G;
     const u32 job_idx = blockIdx.x * GPW + grp;
@@ -76,88 +96,294 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
     SwJob J{};
     if (live) J = jobs[job_idx];
     const int nrow = (int)J.len1, ncol = (int)J.len2;
+    const int n_own = TR ? ncol : nrow, n_swp = TR ? nrow : ncol;      // positions spread over the lanes | positions swept
     const bool indel = J.strategy == MGX_SW_INDEL || J.strategy == MGX_SW_LEADING_INDEL;
-    const u8* a = s1 + J.off1;
-    const u8* b = s2 + J.off2;
-    int32_t* last_row = sc + J.sc_off;
-    int32_t* last_col = last_row + ncol + 1;
+    const u8* own = TR ? s2 + J.off2 : s1 + J.off1;
+    const u8* swp = TR ? s1 + J.off1 : s2 + J.off2;
+    int32_t* last_row = sc + J.sc_off;               // H(nrow, j), j = 1 .. ncol
+    int32_t* last_col = last_row + ncol + 1;         // H(i, ncol), i = 1 .. nrow
+    int32_t* const edge_own = TR ? last_col : last_row;      // written step by step by the lane that owns the last position
+    int32_t* const edge_swp = TR ? last_row : last_col;      // the registers after the last step
     u8* btp = bt + J.bt_off;
     u8* sh_b = sh_all + (size_t)grp * lds_stride;
-    for (int x = lane; x < ncol; x += G) sh_b[x] = b[x];
+    for (int x = lane; x < n_swp; x += G) sh_b[x] = swp[x];
     __syncthreads();
-    const int r0 = lane * RPL;                       // this lane owns rows r0+1 .. r0+RPL (1-based)
-    int sa[RPL], hl[RPL], e[RPL];
+    const int r0 = lane * RPL;                       // this lane owns positions r0+1 .. r0+RPL (1-based)
+    int sa[RPL], hl[RPL], gs[RPL];                   // gs: the gap state along the sweep (E when the lanes own rows, F when columns)
 #pragma unroll
     for (int k = 0; k < RPL; ++k) {
         const int i = r0 + k + 1;
-        sa[k] = (live && i <= nrow) ? (int)a[i - 1] : 256;        // padding rows never match and feed nothing above them
-        hl[k] = indel ? P.open + (i - 1) * P.extend : 0;          // H(i, 0), PairWiseSW.h:243-253
-        e[k] = kLowInit;                                          // E(i, 0)
+        sa[k] = (live && i <= n_own) ? (int)own[i - 1] : 256;     // padding positions never match and feed nothing beyond them
+        hl[k] = indel ? P.open + (i - 1) * P.extend : 0;          // H(i, 0) / H(0, j), PairWiseSW.h:243-253
+        gs[k] = kLowInit;                                         // E(i, 0) / F(0, j)
     }
-    int diag_in = r0 == 0 ? 0 : (indel ? P.open + (r0 - 1) * P.extend : 0);   // H(r0, 0)
-    const int n_lanes = live ? (nrow + RPL - 1) / RPL : 0;
-    const int steps = live ? ncol + n_lanes - 1 : 0;
+    int diag_in = r0 == 0 ? 0 : (indel ? P.open + (r0 - 1) * P.extend : 0);   // H(r0, 0) / H(0, r0)
+    const int n_lanes = live ? (n_own + RPL - 1) / RPL : 0;
+    const int steps = live ? n_swp + n_lanes - 1 : 0;
     int steps_w = steps;                              // the wavefront walks to its longest pair
     if constexpr (GPW > 1) {
         const int other = __shfl_xor(steps, G, 64);
         steps_w = other > steps ? other : steps;
     }
-    const int lane_last = live ? (nrow - 1) / RPL : -1, k_last = live ? (nrow - 1) % RPL : 0;
-    int send_h = 0, send_f = kLowInit;
+    const int lane_last = live ? (n_own - 1) / RPL : -1, k_last = live ? (n_own - 1) % RPL : 0;
+    int send_h = 0, send_g = kLowInit;
     for (int t = 1; t <= steps_w; ++t) {
-        // what the lane above computed for this column one step ago: H(r0, j), F(r0, j)
-        const int rh = __shfl_up(send_h, 1, G), rf = __shfl_up(send_f, 1, G);
-        const int j = t - lane;
-        if (j >= 1 && j <= ncol && lane < n_lanes) {
-            int up_h, up_f, diag;
+        // what the lane before computed for this sweep position one step ago: H and the chained gap at its last position
+        const int rh = __shfl_up(send_h, 1, G), rg = __shfl_up(send_g, 1, G);
+        const int j = t - lane;                       // the sweep position of this lane at this step
+        if (j >= 1 && j <= n_swp && lane < n_lanes) {
+            int up_h, up_g, diag;
             if (lane == 0) {
-                up_h = indel ? P.open + (j - 1) * P.extend : 0;                           // H(0, j)
-                up_f = kLowInit;                                                          // F(0, j)
-                diag = j == 1 ? 0 : (indel ? P.open + (j - 2) * P.extend : 0);            // H(0, j-1), H(0,0) = 0
-            } else { up_h = rh; up_f = rf; diag = diag_in; }
-            diag_in = up_h;                                          // H(r0, j) is the diagonal of column j+1
+                up_h = indel ? P.open + (j - 1) * P.extend : 0;                           // H(0, j) / H(i, 0)
+                up_g = kLowInit;                                                          // F(0, j) / E(i, 0)
+                diag = j == 1 ? 0 : (indel ? P.open + (j - 2) * P.extend : 0);            // the boundary one position back, H(0,0) = 0
+            } else { up_h = rh; up_g = rg; diag = diag_in; }
+            diag_in = up_h;                                          // this step's neighbour value is the next step's diagonal
             const int c2 = (int)sh_b[j - 1];
             u32 packed[(RPL + 3) / 4];
 #pragma unroll
             for (int q = 0; q < (RPL + 3) / 4; ++q) packed[q] = 0;
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
-                const int open_h = hl[k] + P.open, ext_h = e[k] + P.extend;
-                const int ee = max(open_h, ext_h);
-                int ext = open_h > ext_h ? 0 : kInsertExt;
-                const int open_v = up_h + P.open, ext_v = up_f + P.extend;
-                const int ff = max(ext_v, open_v);
-                if (!(open_v > ext_v)) ext |= kDeleteExt;
+                const int open_s = hl[k] + P.open, ext_s = gs[k] + P.extend;         // along the sweep
+                const int gs_new = max(open_s, ext_s);
+                const int open_c = up_h + P.open, ext_c = up_g + P.extend;           // along the lanes' own positions
+                const int gc_new = max(ext_c, open_c);
+                // E is the horizontal gap (INSERT), F the vertical one (DELETE); ties prefer the extension
+                int ext = 0;
+                if (!(open_s > ext_s)) ext |= TR ? kDeleteExt : kInsertExt;
+                if (!(open_c > ext_c)) ext |= TR ? kInsertExt : kDeleteExt;
+                const int ee = TR ? gc_new : gs_new, ff = TR ? gs_new : gc_new;
                 int h = max(diag + (sa[k] == c2 ? P.match : P.mismatch), kMinCutoff);
                 int op = kOpMatch;
                 if (ee > h) { op = kOpInsert; h = ee; }
                 if (ff > h) { op = kOpDelete; h = ff; }
-                diag = hl[k]; hl[k] = h; e[k] = ee; up_h = h; up_f = ff;
+                diag = hl[k]; hl[k] = h; gs[k] = gs_new; up_h = h; up_g = gc_new;
                 packed[k >> 2] |= (u32)(op | ext) << ((k & 3) * 8);
             }
-            send_h = up_h; send_f = up_f;
+            send_h = up_h; send_g = up_g;
             if (lane == lane_last) {
                 int v = hl[0];
 #pragma unroll
                 for (int k = 1; k < RPL; ++k) if (k == k_last) v = hl[k];
-                last_row[j] = v;
+                edge_own[j] = v;
             }
-            u8* dst = btp + ((size_t)t * G + lane) * RPL;
+            constexpr int SLOT = bt_slot(RPL);
+            u8* dst = btp + ((size_t)t * G + lane) * SLOT;
             if constexpr (RPL == 1) dst[0] = (u8)packed[0];
             else if constexpr (RPL == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed[0];
             else {
 #pragma unroll
-                for (int q = 0; q < RPL / 4; ++q) reinterpret_cast<u32*>(dst)[q] = packed[q];
+                for (int q = 0; q < SLOT / 4; ++q) reinterpret_cast<u32*>(dst)[q] = packed[q];
             }
         }
     }
-    // a lane's last active step is column ncol: its registers now hold H(i, ncol) (kept out of the loop --
+    // a lane's last active step is the last sweep position: its registers now hold H there (kept out of the loop --
     // a guarded store per cell and step doubled the instruction count of the sweep)
     if (lane < n_lanes) {
 #pragma unroll
-        for (int k = 0; k < RPL; ++k) if (r0 + k + 1 <= nrow) last_col[r0 + k + 1] = hl[k];
+        for (int k = 0; k < RPL; ++k) if (r0 + k + 1 <= n_own) edge_swp[r0 + k + 1] = hl[k];
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same fill with packed 16-bit scores (round 3).  The 32-bit sweep issues ~26 integer instructions per cell (compare + select for
+// every tie rule and flag); here a lane group carries TWO pairs, one in each half of every register (v_pk_add / v_pk_max / v_pk_sub _i16),
+// and the four decisions of a cell -- E opened, F opened, E beats the diagonal, F beats both -- are the SIGN BITS of four packed
+// differences, merged with v_bfi into one nibble per pair: ~25 instructions per two cells.  Values are the reference's exactly as long
+// as nothing wraps: the host admits a pair only when every real value and every difference of two of them fits 16 bits
+// (fits_i16 below: bounds from the lengths and the scoring parameters; LOW_INIT_VALUE becomes a per-pair value below every real one),
+// everything else takes k_sw_fill.  Cells outside a pair's own matrix (the other half is longer, padding rows) may wrap: nothing real
+// reads them.
+//   * back-trace: one 32-bit word per lane, step and four rows: low half = the first pair's four nibbles (row 4q in bits 0-3),
+//     high half = the second pair's; nibble = {8: E opened, 4: F opened, 2: E > diagonal, 1: F > max(diagonal, E)}
+//   * H(nrow, j): the lane that owns a pair's last row stores its RPL packed H values per step (three or four store instructions;
+//     picking the one row out of the registers would cost RPL selects per step); the trace kernels read row (nrow - 1) % RPL of it
+//   * H(i, ncol): every lane stores its RPL packed H values when it passes the pair's last column (the other pair may sweep on)
+//   * every class of a batch runs in ONE launch (a wave-uniform switch over RPL; classes are padded to whole wavefronts with filler
+//     jobs): 20 000 pairs are 5 000 wavefronts -- per-class launches of a few hundred wavefronts each would leave the device idle.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk2(int lo, int hi) { s16x2 v; v.x = (short)lo; v.y = (short)hi; return v; }
+__device__ __forceinline__ u32 bits(s16x2 v) { return __builtin_bit_cast(u32, v); }
+__device__ __forceinline__ s16x2 s16(u32 v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+// (a & mask) | (b & ~mask) in one instruction; written out, the compiler splits it into v_and + v_and_or (no 32-bit literals in VOP3 on gfx9)
+__device__ __forceinline__ u32 bfi(u32 mask, u32 a, u32 b) { u32 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b)); return r; }
+// 1 in every half whose bases differ (as a compare it becomes two 16-bit compares, two selects and a v_perm)
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) { u32 r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ s16x2 pk_mad(u32 a, s16x2 b, s16x2 c) { u32 r; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(bits(b)), "v"(bits(c))); return s16(r); }
+__host__ __device__ constexpr int bt_slot16(int rpl) { return 4 * ((rpl + 3) / 4); }
+
+template <int G, int RPL>
+__device__ __forceinline__ void sw_fill16_body(const SwJob& JA, const SwJob& JB, const int lane, const u8* __restrict__ s1, const u8* __restrict__ s2,
+                                               u8* __restrict__ bt, int32_t* __restrict__ sc, u32* sh, const SwParams P) {
+    constexpr int GPW = 64 / G;
+    constexpr int W = (RPL + 3) / 4;                  // back-trace words per lane and step
+    const int nrowA = (int)JA.len1, ncolA = (int)JA.len2, nrowB = (int)JB.len1, ncolB = (int)JB.len2;
+    const int n_swp = max(ncolA, ncolB);
+    const bool indelA = JA.strategy == MGX_SW_INDEL || JA.strategy == MGX_SW_LEADING_INDEL;
+    const bool indelB = JB.strategy == MGX_SW_INDEL || JB.strategy == MGX_SW_LEADING_INDEL;
+    const u8* rowsA = s1 + JA.off1; const u8* rowsB = s1 + JB.off1;
+    const u8* colsA = s2 + JA.off2; const u8* colsB = s2 + JB.off2;
+    for (int x = lane; x < n_swp; x += G) sh[x] = (x < ncolA ? (u32)colsA[x] : 0u) | ((x < ncolB ? (u32)colsB[x] : 0u) << 16);
+    __syncthreads();
+    const int r0 = lane * RPL;
+    const s16x2 vopen = pk2(P.open, P.open), vext = pk2(P.extend, P.extend), vmatch = pk2(P.match, P.match);
+    const s16x2 vdelta = pk2(P.mismatch - P.match, P.mismatch - P.match);
+    const s16x2 vlow = pk2(JA.low16, JB.low16);
+    u32 sa[RPL];
+    s16x2 hl[RPL], gs[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+        const int i = r0 + k + 1;
+        sa[k] = (i <= nrowA ? (u32)rowsA[i - 1] : 256u) | ((i <= nrowB ? (u32)rowsB[i - 1] : 256u) << 16);
+        hl[k] = pk2(indelA ? P.open + (i - 1) * P.extend : 0, indelB ? P.open + (i - 1) * P.extend : 0);     // H(i, 0)
+        gs[k] = vlow;                                                                                       // E(i, 0)
+    }
+    s16x2 diag_in = r0 == 0 ? pk2(0, 0) : pk2(indelA ? P.open + (r0 - 1) * P.extend : 0, indelB ? P.open + (r0 - 1) * P.extend : 0);   // H(r0, 0)
+    s16x2 bnd = pk2(indelA ? P.open : 0, indelB ? P.open : 0);                      // lane 0: H(0, j), starting at j = 1
+    const s16x2 bstep = pk2(indelA ? P.extend : 0, indelB ? P.extend : 0);
+    const int n_lanes = max((nrowA + RPL - 1) / RPL, (nrowB + RPL - 1) / RPL);
+    const int steps = n_lanes > 0 ? n_swp + n_lanes - 1 : 0;
+    int steps_w = steps;
+    if constexpr (GPW > 1) {
+        const int other = __shfl_xor(steps, G, 64);
+        steps_w = other > steps ? other : steps;
+    }
+    const int lane_lastA = nrowA > 0 ? (nrowA - 1) / RPL : -1, lane_lastB = nrowB > 0 ? (nrowB - 1) / RPL : -1;
+    u32* const lrA = reinterpret_cast<u32*>(bt + JA.lr_off);
+    u32* const lrB = reinterpret_cast<u32*>(bt + JB.lr_off);
+    const bool lr_apart = JA.lr_off != JB.lr_off;
+    u32* const lcA = reinterpret_cast<u32*>(bt + JA.lc_off);
+    u32* const lcB = reinterpret_cast<u32*>(bt + JB.lc_off);
+    const bool lc_apart = JA.lc_off != JB.lc_off;
+    u8* const btp = bt + JA.bt_off;
+    s16x2 send_h = pk2(0, 0), send_g = vlow;
+    for (int t = 1; t <= steps_w; ++t) {
+        const u32 rh = (u32)__builtin_amdgcn_update_dpp(0, (int)bits(send_h), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const u32 rg = (u32)__builtin_amdgcn_update_dpp(0, (int)bits(send_g), 0x138, 0xf, 0xf, false);
+        const int j = t - lane;
+        if (j >= 1 && j <= n_swp && lane < n_lanes) {
+            s16x2 up_h = lane == 0 ? bnd : s16(rh);                  // H(r0, j)
+            s16x2 up_g = lane == 0 ? vlow : s16(rg);                 // F(r0, j)
+            bnd += bstep;
+            s16x2 diag = diag_in;                                    // H(r0, j - 1)
+            diag_in = up_h;
+            const u32 c2 = sh[j - 1];
+            u32 word[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) word[q] = 0;
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                const s16x2 open_s = hl[k] + vopen, ext_s = gs[k] + vext;
+                const s16x2 ee = pk_max(open_s, ext_s);
+                const s16x2 open_c = up_h + vopen, ext_c = up_g + vext;
+                const s16x2 ff = pk_max(ext_c, open_c);
+                const u32 ne = pk_min_u16(sa[k] ^ c2, 0x00010001u);                                    // 1 where the bases differ
+                const s16x2 h0 = diag + pk_mad(ne, vdelta, vmatch);
+                const s16x2 m1 = pk_max(h0, ee);
+                const s16x2 h = pk_max(m1, ff);
+                // sign bit set: E opened (no INSERT_EXT) | F opened (no DELETE_EXT) | ee > h0 | ff > max(h0, ee)
+                const u32 t1 = bits(ext_s - open_s), t2 = bits(ext_c - open_c), t3 = bits(h0 - ee), t4 = bits(m1 - ff);
+                const u32 u12 = bfi(0x80008000u, t1, t2 >> 1), u34 = bfi(0x80008000u, t3, t4 >> 1);
+                const u32 nib = bfi(0xC000C000u, u12, u34 >> 2);
+                word[k >> 2] = bfi(0xF000F000u, nib, word[k >> 2] >> 4);
+                diag = hl[k]; hl[k] = h; gs[k] = ee; up_h = h; up_g = ff;
+            }
+            if constexpr (RPL % 4 != 0) word[W - 1] >>= 4 * (4 - RPL % 4);
+            send_h = up_h; send_g = up_g;
+            u32* dst = reinterpret_cast<u32*>(btp + ((size_t)t * G + lane) * (4 * W));
+#pragma unroll
+            for (int q = 0; q < W; ++q) dst[q] = word[q];
+            if (lane == lane_lastA) {
+                u32* d = lrA + (size_t)j * RPL;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) d[k] = bits(hl[k]);
+            }
+            if (lr_apart && lane == lane_lastB) {
+                u32* d = lrB + (size_t)j * RPL;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) d[k] = bits(hl[k]);
+            }
+            if (j == ncolA) {
+                u32* d = lcA + r0;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) d[k] = bits(hl[k]);
+            }
+            if (lc_apart && j == ncolB) {
+                u32* d = lcB + r0;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) d[k] = bits(hl[k]);
+            }
+        }
+    }
+}
+
+// jobs: pairs 2g and 2g + 1 share lane group g; both of one class (rpl), a class ends on a wavefront boundary.  BIG: the classes of
+// more than 16 rows per lane, a kernel of their own (178 registers; the common one keeps 100 and twice the wavefronts per SIMD)
+template <int G, bool BIG>
+__global__ __launch_bounds__(64) void k_sw_fill16(const SwJob* __restrict__ jobs, u32 n_jobs, const u8* __restrict__ s1, const u8* __restrict__ s2,
+                                                  u8* __restrict__ bt, int32_t* __restrict__ sc, u32 lds_stride, SwParams P) {
+    extern __shared__ u32 sh16_all[];
+    constexpr int GPW = 64 / G;
+    const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+    const u32 g = blockIdx.x * GPW + grp;
+    SwJob JA{}, JB{};
+    if (2 * g < n_jobs) { JA = jobs[2 * g]; JB = jobs[2 * g + 1]; }
+    u32* sh = sh16_all + (size_t)grp * lds_stride;
+    const int rpl = __builtin_amdgcn_readfirstlane((int)jobs[2 * (size_t)blockIdx.x * GPW].rpl);       // the wavefront's class
+#define MGX_SW16_CASE(r) case r: sw_fill16_body<G, r>(JA, JB, lane, s1, s2, bt, sc, sh, P); break;
+    if constexpr (BIG) {
+        switch (rpl) {
+            MGX_SW16_CASE(20) MGX_SW16_CASE(24) MGX_SW16_CASE(32)
+            default: break;
+        }
+    } else {
+        switch (rpl) {
+            MGX_SW16_CASE(1) MGX_SW16_CASE(2) MGX_SW16_CASE(3) MGX_SW16_CASE(4) MGX_SW16_CASE(5) MGX_SW16_CASE(6) MGX_SW16_CASE(7) MGX_SW16_CASE(8)
+            MGX_SW16_CASE(9) MGX_SW16_CASE(10) MGX_SW16_CASE(11) MGX_SW16_CASE(12) MGX_SW16_CASE(13) MGX_SW16_CASE(14) MGX_SW16_CASE(16)
+            default: break;
+        }
+    }
+#undef MGX_SW16_CASE
+}
+
+// what the trace kernels read of a pair's back-trace, whichever kernel filled it: the byte of the 32-bit form (op | INSERT_EXT | DELETE_EXT)
+struct BtView {
+    const u8* p; int rpl, g, slot; bool tr, i16; int half;
+    __device__ BtView(const SwJob& J, const u8* bt) : p(bt + J.bt_off), rpl((int)J.rpl), g((int)(J.g & 0xFFu)), tr((J.g & kJobTr) != 0),
+                                                     i16((J.g & kJobI16) != 0), half((J.g & kJobHalf) ? 1 : 0) {
+        slot = i16 ? bt_slot16(rpl) : bt_slot(rpl);
+    }
+    __device__ int cell(int i, int j) const {
+        const int o = tr ? j : i, w = tr ? i : j;                      // position among the lanes | swept position
+        const int l = (o - 1) / rpl, k = (o - 1) - l * rpl;
+        const size_t base = ((size_t)(w + l) * g + l) * slot;
+        if (!i16) return p[base + k];
+        const int by = p[base + (k >> 2) * 4 + half * 2 + ((k & 3) >> 1)];
+        const int nib = (k & 1) ? by >> 4 : by & 15;
+        return ((nib & 1) ? kOpDelete : (nib & 2) ? kOpInsert : kOpMatch) | ((nib & 8) ? 0 : kInsertExt) | ((nib & 4) ? 0 : kDeleteExt);
+    }
+};
+// H(nrow, j), j = 1 .. ncol
+struct LastRow {
+    const int32_t* p32; const u32* p16; int rpl, k_last, half;
+    __device__ LastRow(const SwJob& J, const u8* bt, const int32_t* sc) : p32(sc + J.sc_off), p16(reinterpret_cast<const u32*>(bt + J.lr_off)),
+                                                                            rpl((int)J.rpl), k_last(((int)J.len1 - 1) % (int)J.rpl), half((J.g & kJobHalf) ? 16 : 0) {
+        if (!(J.g & kJobI16)) p16 = nullptr;
+    }
+    __device__ int operator[](int j) const { return p16 ? (int)(int16_t)(p16[(size_t)j * rpl + k_last] >> half) : p32[j]; }
+};
+// H(i, ncol), i = 1 .. nrow
+struct LastCol {
+    const int32_t* p32; const u32* p16; int half;
+    __device__ LastCol(const SwJob& J, const u8* bt, const int32_t* sc) : p32(sc + J.sc_off + J.len2 + 1), p16(reinterpret_cast<const u32*>(bt + J.lc_off)),
+                                                                            half((J.g & kJobHalf) ? 16 : 0) {
+        if (!(J.g & kJobI16)) p16 = nullptr;
+    }
+    __device__ int operator[](int i) const { return p16 ? (int)(int16_t)(p16[i - 1] >> half) : p32[i]; }
+};
 
 // One lane per pair: best end cell, back-trace, merged element list (in the order getCIGAR holds it).
 __global__ __launch_bounds__(64) void k_sw_trace(const SwJob* __restrict__ jobs, u32 n, const u8* __restrict__ bt,
@@ -166,10 +392,11 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwJob* __restrict__ jobs,
     const u32 p = blockIdx.x * 64 + threadIdx.x;
     if (p >= n) return;
     const SwJob J = jobs[p];
-    const int nrow = (int)J.len1, ncol = (int)J.len2, strategy = (int)J.strategy, rpl = (int)J.rpl, g = (int)J.g;
-    const int32_t* last_row = sc + J.sc_off;
-    const int32_t* last_col = last_row + ncol + 1;
-    const u8* btp = bt + J.bt_off;
+    if (J.out_index == kNoOutput) return;
+    const int nrow = (int)J.len1, ncol = (int)J.len2, strategy = (int)J.strategy;
+    const LastRow last_row(J, bt, sc);
+    const LastCol last_col(J, bt, sc);
+    const BtView view(J, bt);
     int16_t* el = elems_all + J.el_off;
     // PairWiseSW.h:256-285, in anti-diagonal order
     int best = INT32_MIN, mi = 0, mj = 0;
@@ -193,8 +420,7 @@ __global__ __launch_bounds__(64) void k_sw_trace(const SwJob* __restrict__ jobs,
     if (j < ncol) { el[0] = MGX_SW_SOFTCLIP; el[1] = (int16_t)(ncol - j); m = 1; }
     int state = 0;
     while (i > 0 && j > 0) {
-        const int l = (i - 1) / rpl, k = (i - 1) - l * rpl;
-        const int btr = btp[((size_t)(j + l) * g + l) * rpl + k];
+        const int btr = view.cell(i, j);
         if (state == kInsertExt) { --j; el[2 * m - 1]++; state = btr & kInsertExt; }
         else if (state == kDeleteExt) { --i; el[2 * m - 1]++; state = btr & kDeleteExt; }
         else {
@@ -243,10 +469,11 @@ __global__ __launch_bounds__(64) void k_sw_trace_wave(const SwJob* __restrict__ 
     if (p >= n) return;
     const int lane = threadIdx.x;
     const SwJob J = jobs[p];
-    const int nrow = (int)J.len1, ncol = (int)J.len2, strategy = (int)J.strategy, rpl = (int)J.rpl, g = (int)J.g;
-    const int32_t* last_row = sc + J.sc_off;
-    const int32_t* last_col = last_row + ncol + 1;
-    const u8* btp = bt + J.bt_off;
+    if (J.out_index == kNoOutput) return;
+    const int nrow = (int)J.len1, ncol = (int)J.len2, strategy = (int)J.strategy;
+    const LastRow last_row(J, bt, sc);
+    const LastCol last_col(J, bt, sc);
+    const BtView view(J, bt);
     int16_t* el = elems_all + J.el_off;
     const bool use_row = strategy == MGX_SW_SOFTCLIP || strategy == MGX_SW_IGNORE;
     // ---- best end cell (PairWiseSW.h:256-285).  The maximum first, in parallel; then the cells that reach it are
@@ -294,10 +521,6 @@ __global__ __launch_bounds__(64) void k_sw_trace_wave(const SwJob* __restrict__ 
         else { flush(); cur_op = op; cur_len = len; }
     };
     if (j < ncol) push(MGX_SW_SOFTCLIP, ncol - j);
-    auto cell_index = [&](int ii, int jj) -> size_t {
-        const int l = (ii - 1) / rpl, k = (ii - 1) - l * rpl;
-        return ((size_t)(jj + l) * g + l) * rpl + k;
-    };
     int state = 0;
     int c_i = 0, c_j = 0;         // the cached diagonal starts at (c_i, c_j): lane t holds cell (c_i - t, c_j - t)
     int cached = 0;
@@ -309,11 +532,11 @@ __global__ __launch_bounds__(64) void k_sw_trace_wave(const SwJob* __restrict__ 
             if (!valid || t < 0 || t >= 64 || c_j - j != t) {
                 c_i = i; c_j = j; valid = true; t = 0;
                 const int ii = i - lane, jj = j - lane;
-                cached = (ii >= 1 && jj >= 1) ? (int)btp[cell_index(ii, jj)] : 0;
+                cached = (ii >= 1 && jj >= 1) ? view.cell(ii, jj) : 0;
             }
             btr = __builtin_amdgcn_readlane(cached, __builtin_amdgcn_readfirstlane(t));
         } else {
-            btr = btp[cell_index(i, j)];
+            btr = view.cell(i, j);
         }
         if (state == kInsertExt) { --j; cur_len++; state = btr & kInsertExt; }
         else if (state == kDeleteExt) { --i; cur_len++; state = btr & kDeleteExt; }
@@ -356,25 +579,65 @@ __global__ __launch_bounds__(256) void k_sw_gather(const GatherRef* __restrict__
     }
 }
 
-// lanes per pair and rows per lane: two pairs share a wavefront up to 512 reference bases
-struct Shape { int g, rpl; };
-// `paired`: batches large enough to fill the device twice over put two pairs on a wavefront (better lane
-// use, fewer diagonal fill/drain steps); smaller batches keep one pair per wavefront so that every SIMD
-// still has several wavefronts to hide the dependent integer chain of a step behind.
-Shape shape_for(int nrow, bool paired) {
+// lanes per pair, positions per lane, and which sequence the lanes own
+struct Shape { int g, rpl; bool tr; };
+// The lanes own the SHORTER sequence (round 3: the read, in the realignment workload) and sweep the longer one: fewer padding
+// positions and fewer fill/drain steps per useful step (k_sw_fill<.., TR>).  Up to 256 owned positions two pairs share a
+// wavefront (32 lanes x 1..8) whenever the batch is large enough to fill the device that way; otherwise, and beyond, one pair
+// per wavefront (64 lanes x 1..32) so that every SIMD still has several wavefronts to hide the dependent integer chain of a
+// step behind.  MGX_SW_TRANSPOSE=0 keeps the lanes on the reference (round 2's shapes; A/B and tests).
+Shape shape_for(int len1, int len2, bool paired) {
+    const char* e_tr = getenv("MGX_SW_TRANSPOSE");
+    const int transpose = e_tr ? atoi(e_tr) : 0;
+    const bool tr = transpose != 0 && len2 < len1;
+    const int n_own = tr ? len2 : len1;
     if (paired) {
-        static const int cls32[] = {1, 2, 4, 8, 12, 16};
-        for (int r : cls32) if (nrow <= 32 * r) return Shape{32, r};
+        static const int cls32[] = {1, 2, 3, 4, 5, 6, 7, 8, 12, 16};
+        for (int r : cls32) if (n_own <= 32 * r) return Shape{32, r, tr};
     }
-    static const int cls64[] = {1, 2, 4, 8, 16, 32};
-    for (int r : cls64) if (nrow <= 64 * r) return Shape{64, r};
-    return Shape{0, 0};
+    static const int cls64[] = {1, 2, 3, 4, 5, 6, 8, 16, 32};
+    for (int r : cls64) if (n_own <= 64 * r) return Shape{64, r, tr};
+    return Shape{0, 0, false};
 }
-constexpr u32 kPairedFrom = 32768;            // pairs in a chunk from which two share a wavefront
+constexpr u32 kPairedFrom = 8192;             // pairs in a chunk from which two lane groups share a wavefront (round 2: 32768)
+
+// ---- the packed 16-bit fill (k_sw_fill16): shapes and admission
+Shape shape16_for(int len1, bool paired) {
+    static const int cls[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 20, 24, 32};
+    if (paired) for (int r : cls) if (len1 <= 32 * r) return Shape{32, r, false};
+    for (int r : cls) if (len1 <= 64 * r) return Shape{64, r, false};
+    return Shape{0, 0, false};
+}
+// Every value k_sw_fill16 computes for a cell of the pair's own matrix, and every difference of two of them, must fit 16 bits.
+//   H(i, j) >= the all-diagonal path from the boundary: blo + min(len) * min(match, mismatch, 0)
+//   any H, E, F <= the best a path can collect: bhi + min(len) * max(match, mismatch, 0) when gaps cost (open, extend <= 0)
+//   one more open / extend / match on top of either: `pad`
+// LOW_INIT_VALUE only ever meets a real value as LOW + extend against H + open (first column of E, first row of F) and must lose
+// strictly: low = L - |extend| - 1.  MATRIX_MIN_CUTOFF (-1e8) cannot bind inside 16 bits.
+bool fits_i16(int64_t n, int64_t m, const SwParams& P, int32_t* low16) {
+    if (m > 4096) return false;                          // two alternates per lane group are staged in LDS as 32-bit words
+    const int64_t mx = std::max(n, m), mn = std::min(n, m);
+    const int64_t dlo = std::min<int64_t>(P.match, P.mismatch), dhi = std::max<int64_t>(P.match, P.mismatch);
+    const int64_t b_end = (int64_t)P.open + (mx - 1) * (int64_t)P.extend;
+    const int64_t blo = std::min<int64_t>({0, P.open, b_end}), bhi = std::max<int64_t>({0, P.open, b_end});
+    const int64_t pos = std::max<int64_t>({dhi, P.open, P.extend, 0});
+    const int64_t u0 = (P.open <= 0 && P.extend <= 0) ? bhi + mn * std::max<int64_t>(dhi, 0) : bhi + (n + m) * pos;
+    const int64_t lh = blo + mn * std::min<int64_t>(dlo, 0);
+    const int64_t a_ext = std::llabs((long long)P.extend);
+    const int64_t pad = std::llabs((long long)P.open) + a_ext + std::max(std::llabs((long long)P.match), std::llabs((long long)P.mismatch));
+    const int64_t lo = lh - pad, up = u0 + pad;
+    const int64_t low = lo - a_ext - 1, ll = low - a_ext;
+    if (ll < -32768 || up > 32767 || up - ll > 32767) return false;
+    *low16 = (int32_t)low;
+    return true;
+}
+inline u64 bt_bytes16(u64 steps_max, const Shape& sh) { return ((steps_max + 1) * sh.g * bt_slot16(sh.rpl) + 15) & ~15ull; }
+inline u64 lr_bytes16(u64 n_swp, const Shape& sh) { return ((n_swp + 1) * sh.rpl * 4 + 15) & ~15ull; }
 constexpr int kCompactElems = 16;             // merged CIGAR elements copied back per pair without a second look
 inline u64 bt_bytes(u64 len1, u64 len2, const Shape& sh) {
-    const u64 n_lanes = (len1 + sh.rpl - 1) / sh.rpl, steps = len2 + n_lanes - 1;
-    return ((steps + 1) * sh.g * sh.rpl + 15) & ~15ull;
+    const u64 n_own = sh.tr ? len2 : len1, n_swp = sh.tr ? len1 : len2;
+    const u64 n_lanes = (n_own + sh.rpl - 1) / sh.rpl, steps = n_swp + n_lanes - 1;
+    return ((steps + 1) * sh.g * bt_slot(sh.rpl) + 15) & ~15ull;
 }
 
 int itoa_len(int v) { const int neg = v < 0; if (neg) v = -v; int d = 0; while (v > 0) { v /= 10; ++d; } return d + neg; }
@@ -436,51 +699,120 @@ namespace {
 constexpr u64 kArenaLimit = 4ull << 30;
 
 template <int G, int RPL>
-void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, u32 max_len2, SwParams P) {
+void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, u32 max_swept, bool tr, SwParams P) {
     constexpr u32 GPW = 64 / G;
-    const u32 stride = (max_len2 + 15) & ~15u;
-    hipLaunchKernelGGL((k_sw_fill<G, RPL>), dim3((n + GPW - 1) / GPW), dim3(64), GPW * stride, c->stream, jobs, n, c->d_s1.p, c->d_s2.p,
-                       c->d_bt.p, c->d_sc.p, stride, P);
+    const u32 stride = (max_swept + 15) & ~15u;
+    if (tr) hipLaunchKernelGGL((k_sw_fill<G, RPL, true>), dim3((n + GPW - 1) / GPW), dim3(64), GPW * stride, c->stream, jobs, n, c->d_s1.p, c->d_s2.p,
+                               c->d_bt.p, c->d_sc.p, stride, P);
+    else    hipLaunchKernelGGL((k_sw_fill<G, RPL, false>), dim3((n + GPW - 1) / GPW), dim3(64), GPW * stride, c->stream, jobs, n, c->d_s1.p, c->d_s2.p,
+                               c->d_bt.p, c->d_sc.p, stride, P);
 }
 
 // pairs [lo, hi) of the input, already validated
 int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in, u64 lo, u64 hi,
               int32_t* out_offset, char* out_cigar, u32 stride, int32_t* out_score, int cap_override) {
     const u32 n = (u32)(hi - lo);
+    static const bool prof = [] { const char* e = getenv("MGX_SW_PROF"); return e && atoi(e) != 0; }();      // host stage times on stderr
+    double tp[6] = {0};
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    tp[0] = now();
     bool paired = n >= kPairedFrom;
     if (const char* e = getenv("MGX_SW_PAIRED")) paired = atoi(e) != 0;      // tests: force either shape family
-    std::vector<SwJob> jobs(n);
+    bool use16 = true;
+    if (const char* e = getenv("MGX_SW_I16")) use16 = atoi(e) != 0;          // 0: the 32-bit fill for every pair (A/B, tests)
+    const SwParams P{params->match, params->mismatch, params->gap_open, params->gap_extend};
     const u64 base1 = in->ref_off[lo], base2 = in->alt_off[lo];
-    u64 bt = 0, scn = 0, eln = 0;
+    // jobs in input order first (score and element arenas are laid out in that order), then sorted into launch order:
+    // the packed 16-bit classes first (32 lanes, then 64; most rows per lane first), the 32-bit classes after them,
+    // longest alternate first inside a class (the two pairs of a lane group and the groups of a wavefront finish together;
+    // a launch drains on its cheapest jobs).  Two counting sorts: a comparison sort of 10^5 jobs costs more than their alignments.
+    std::vector<SwJob> pre(n);
+    std::vector<uint16_t> cls(n);
+    u64 scn = 0, eln = 0;
     for (u32 q = 0; q < n; ++q) {
         const u64 p = lo + q;
-        SwJob& J = jobs[q];
+        SwJob& J = pre[q];
+        J = SwJob{};
         J.off1 = in->ref_off[p] - base1; J.off2 = in->alt_off[p] - base2;
         J.len1 = (u32)(in->ref_off[p + 1] - in->ref_off[p]); J.len2 = (u32)(in->alt_off[p + 1] - in->alt_off[p]);
-        const Shape sh = shape_for((int)J.len1, paired);
-        J.rpl = (u32)sh.rpl; J.g = (u32)sh.g; J.strategy = in->strategy[p]; J.out_index = q;
-        J.bt_off = bt; bt += bt_bytes(J.len1, J.len2, sh);
+        J.strategy = in->strategy[p]; J.out_index = q;
         J.sc_off = scn; scn += (u64)J.len1 + J.len2 + 2;
         J.el_off = eln; eln += 2 * ((u64)J.len1 + J.len2 + 2);
+        if (use16 && fits_i16(J.len1, J.len2, P, &J.low16)) {
+            const Shape sh = shape16_for((int)J.len1, paired);
+            J.rpl = (u32)sh.rpl; J.g = (u32)sh.g | kJobI16;
+            cls[q] = (uint16_t)((sh.g == 64 ? 64 : 0) + (32 - sh.rpl));                                  // < 128
+            c->stats.n_pairs_i16++;
+        } else {
+            const Shape sh = shape_for((int)J.len1, (int)J.len2, paired);
+            J.rpl = (u32)sh.rpl; J.g = (u32)sh.g | (sh.tr ? kJobTr : 0u);
+            cls[q] = (uint16_t)(128 + (sh.g == 64 ? 64 : 0) + (sh.tr ? 128 : 0) + sh.rpl);               // < 384
+        }
     }
-    // one fill launch per row class: sort the job list by rpl (stable; results go back through out_index)
-    {   // counting sort by (g, rpl): a comparison sort of 10^5 jobs costs more than their alignments
-        auto cls = [](const SwJob& j) { return (j.g == 64 ? 64u : 0u) + j.rpl; };           // < 128
-        u32 cnt[129] = {0};
-        for (const SwJob& j : jobs) cnt[cls(j) + 1]++;
-        for (int k = 0; k < 128; ++k) cnt[k + 1] += cnt[k];
-        std::vector<SwJob> sorted(n);
-        for (const SwJob& j : jobs) sorted[cnt[cls(j)]++] = j;
-        jobs.swap(sorted);
+    std::vector<u32> order(n);
+    {
+        std::vector<u32> cnt(32770, 0), tmp(n);
+        for (u32 q = 0; q < n; ++q) cnt[32767 - pre[q].len2 + 1]++;
+        for (u32 k = 0; k < 32768; ++k) cnt[k + 1] += cnt[k];
+        for (u32 q = 0; q < n; ++q) tmp[cnt[32767 - pre[q].len2]++] = q;
+        u32 c2[385] = {0};
+        for (u32 q = 0; q < n; ++q) c2[cls[q] + 1]++;
+        for (int k = 0; k < 384; ++k) c2[k + 1] += c2[k];
+        for (u32 x = 0; x < n; ++x) order[c2[cls[tmp[x]]]++] = tmp[x];
     }
+    std::vector<SwJob> jobs;
+    jobs.reserve(n + 64);
+    u64 bt = 0;
+    for (u32 x = 0; x < n;) {
+        const u32 q0 = order[x];
+        if (pre[q0].g & kJobI16) {
+            // one class: lane groups of two pairs, whole wavefronts
+            const u32 c = cls[q0];
+            const Shape sh{(int)(pre[q0].g & 0xFFu), (int)pre[q0].rpl, false};
+            const u32 per_wave = 2 * (64 / sh.g);
+            u32 y = x;
+            while (y < n && cls[order[y]] == c) ++y;
+            for (u32 z = x; z < y; z += 2) {
+                SwJob A = pre[order[z]], B{};
+                if (z + 1 < y) B = pre[order[z + 1]];
+                else { B.out_index = kNoOutput; B.rpl = A.rpl; B.g = A.g; }
+                B.g |= kJobHalf;
+                auto lanes = [&](const SwJob& j) { return (u64)(j.len1 + sh.rpl - 1) / sh.rpl; };
+                const u64 n_swp = std::max(A.len2, B.len2), steps = n_swp + std::max(lanes(A), lanes(B)) - 1;
+                A.bt_off = B.bt_off = bt; bt += bt_bytes16(steps, sh);
+                A.lr_off = bt; bt += lr_bytes16(n_swp, sh);
+                const bool same_lane = B.len1 > 0 && (A.len1 - 1) / sh.rpl == (B.len1 - 1) / sh.rpl;
+                if (same_lane || B.len1 == 0) B.lr_off = A.lr_off;
+                else { B.lr_off = bt; bt += lr_bytes16(n_swp, sh); }
+                const u64 lc_bytes = (std::max(lanes(A), lanes(B)) * sh.rpl * 4 + 15) & ~15ull;
+                A.lc_off = bt; bt += lc_bytes;
+                if (B.len2 == A.len2 || B.len1 == 0) B.lc_off = A.lc_off;
+                else { B.lc_off = bt; bt += lc_bytes; }
+                jobs.push_back(A); jobs.push_back(B);
+            }
+            while (jobs.size() % per_wave) {                 // filler groups up to the wavefront boundary
+                SwJob F{}; F.out_index = kNoOutput; F.rpl = (u32)sh.rpl; F.g = (u32)sh.g | kJobI16 | (jobs.size() % 2 ? kJobHalf : 0u);
+                jobs.push_back(F);
+            }
+            x = y;
+        } else {
+            SwJob J = pre[q0];
+            const Shape sh{(int)(J.g & 0xFFu), (int)J.rpl, (J.g & kJobTr) != 0};
+            J.bt_off = bt; bt += bt_bytes(J.len1, J.len2, sh);
+            jobs.push_back(J);
+            ++x;
+        }
+    }
+    const u32 n_jobs = (u32)jobs.size();
+    tp[1] = now();
     const u64 n1 = in->ref_off[hi] - base1, n2 = in->alt_off[hi] - base2;
     int rc;
-    if ((rc = c->d_s1.reserve(n1 + 16)) || (rc = c->d_s2.reserve(n2 + 16)) || (rc = c->d_bt.reserve(bt + 16)) || (rc = c->d_jobs.reserve(n)) ||
+    if ((rc = c->d_s1.reserve(n1 + 16)) || (rc = c->d_s2.reserve(n2 + 16)) || (rc = c->d_bt.reserve(bt + 16)) || (rc = c->d_jobs.reserve(n_jobs)) ||
         (rc = c->d_sc.reserve(scn)) || (rc = c->d_el.reserve(eln)) || (rc = c->d_res.reserve(n)) ||
         (rc = c->d_cel.reserve((size_t)n * 2 * kCompactElems))) return rc;
     hipStream_t s = c->stream;
     {
-        const size_t a1 = (n1 + 255) & ~(size_t)255, a2 = (n2 + 255) & ~(size_t)255, total = a1 + a2 + n * sizeof(SwJob);
+        const size_t a1 = (n1 + 255) & ~(size_t)255, a2 = (n2 + 255) & ~(size_t)255, total = a1 + a2 + n_jobs * sizeof(SwJob);
         if (total > c->pin_cap) {
             if (c->pin) (void)hipHostFree(c->pin);
             c->pin = nullptr; c->pin_cap = 0;
@@ -491,7 +823,7 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         const char* src[3] = {reinterpret_cast<const char*>(in->ref + base1), reinterpret_cast<const char*>(in->alt + base2),
                               reinterpret_cast<const char*>(jobs.data())};
         char* dst[3] = {pin, pin + a1, pin + a1 + a2};
-        const size_t len[3] = {(size_t)n1, (size_t)n2, n * sizeof(SwJob)};
+        const size_t len[3] = {(size_t)n1, (size_t)n2, n_jobs * sizeof(SwJob)};
         if (total < (8u << 20)) { for (int k = 0; k < 3; ++k) memcpy(dst[k], src[k], len[k]); }
         else {
             std::thread th[3];
@@ -500,47 +832,61 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         }
         HIP_TRY(hipMemcpyAsync(c->d_s1.p, dst[0], n1, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->d_s2.p, dst[1], n2, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dst[2], n * sizeof(SwJob), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dst[2], n_jobs * sizeof(SwJob), hipMemcpyHostToDevice, s));
     }
-    const SwParams P{params->match, params->mismatch, params->gap_open, params->gap_extend};
     HIP_TRY(hipEventRecord(c->ev[0], s));
-    for (u32 a = 0; a < n;) {
+    tp[2] = now();
+    for (u32 a = 0; a < n_jobs;) {
         u32 b = a;
         u32 m2 = 0;
-        while (b < n && jobs[b].rpl == jobs[a].rpl && jobs[b].g == jobs[a].g) { m2 = std::max(m2, jobs[b].len2); ++b; }
         const SwJob* dj = c->d_jobs.p + a;
-        if (jobs[a].g == 32) {
+        if (jobs[a].g & kJobI16) {
+            // every class of one lane-group width in one launch (two when classes of more than 16 rows per lane are present)
+            const u32 g = jobs[a].g & 0xFFu, gpw = 64 / g;
+            const bool big = jobs[a].rpl > 16;
+            while (b < n_jobs && (jobs[b].g & kJobI16) && (jobs[b].g & 0xFFu) == g && (jobs[b].rpl > 16) == big) { m2 = std::max(m2, jobs[b].len2); ++b; }
+            const u32 stride = (m2 + 15) & ~15u;
+            const dim3 grid((b - a) / (2 * gpw));
+            const size_t lds = gpw * stride * sizeof(u32);
+#define MGX_SW16_LAUNCH(G_, BIG_) hipLaunchKernelGGL((k_sw_fill16<G_, BIG_>), grid, dim3(64), lds, s, dj, b - a, c->d_s1.p, c->d_s2.p, c->d_bt.p, c->d_sc.p, stride, P)
+            if (g == 32) { if (big) MGX_SW16_LAUNCH(32, true); else MGX_SW16_LAUNCH(32, false); }
+            else         { if (big) MGX_SW16_LAUNCH(64, true); else MGX_SW16_LAUNCH(64, false); }
+#undef MGX_SW16_LAUNCH
+            c->stats.n_launches++;
+            a = b;
+            continue;
+        }
+        const bool tr = (jobs[a].g & kJobTr) != 0;
+        while (b < n_jobs && jobs[b].rpl == jobs[a].rpl && jobs[b].g == jobs[a].g) { m2 = std::max(m2, tr ? jobs[b].len1 : jobs[b].len2); ++b; }
+#define MGX_SW_CASE(g, r) case r: launch_fill<g, r>(c, dj, b - a, m2, tr, P); break;
+        if ((jobs[a].g & 0xFFu) == 32) {
             switch (jobs[a].rpl) {
-                case 1: launch_fill<32, 1>(c, dj, b - a, m2, P); break;
-                case 2: launch_fill<32, 2>(c, dj, b - a, m2, P); break;
-                case 4: launch_fill<32, 4>(c, dj, b - a, m2, P); break;
-                case 8: launch_fill<32, 8>(c, dj, b - a, m2, P); break;
-                case 12: launch_fill<32, 12>(c, dj, b - a, m2, P); break;
-                default: launch_fill<32, 16>(c, dj, b - a, m2, P); break;
+                MGX_SW_CASE(32, 1) MGX_SW_CASE(32, 2) MGX_SW_CASE(32, 3) MGX_SW_CASE(32, 4) MGX_SW_CASE(32, 5) MGX_SW_CASE(32, 6) MGX_SW_CASE(32, 7)
+                MGX_SW_CASE(32, 8) MGX_SW_CASE(32, 12)
+                default: launch_fill<32, 16>(c, dj, b - a, m2, tr, P); break;
             }
         } else {
             switch (jobs[a].rpl) {
-                case 1: launch_fill<64, 1>(c, dj, b - a, m2, P); break;
-                case 2: launch_fill<64, 2>(c, dj, b - a, m2, P); break;
-                case 4: launch_fill<64, 4>(c, dj, b - a, m2, P); break;
-                case 8: launch_fill<64, 8>(c, dj, b - a, m2, P); break;
-                case 16: launch_fill<64, 16>(c, dj, b - a, m2, P); break;
-                default: launch_fill<64, 32>(c, dj, b - a, m2, P); break;
+                MGX_SW_CASE(64, 1) MGX_SW_CASE(64, 2) MGX_SW_CASE(64, 3) MGX_SW_CASE(64, 4) MGX_SW_CASE(64, 5) MGX_SW_CASE(64, 6) MGX_SW_CASE(64, 8)
+                MGX_SW_CASE(64, 16)
+                default: launch_fill<64, 32>(c, dj, b - a, m2, tr, P); break;
             }
         }
+#undef MGX_SW_CASE
         c->stats.n_launches++;
         a = b;
     }
     HIP_TRY(hipEventRecord(c->ev[1], s));
     static const bool lane_trace = [] { const char* e = getenv("MGX_SW_TRACE"); return e && !strcmp(e, "lane"); }();   // A/B: one lane per pair
     if (lane_trace)
-        hipLaunchKernelGGL(k_sw_trace, dim3((n + 63) / 64), dim3(64), 0, s, c->d_jobs.p, n, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
+        hipLaunchKernelGGL(k_sw_trace, dim3((n_jobs + 63) / 64), dim3(64), 0, s, c->d_jobs.p, n_jobs, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
                            c->d_cel.p, kCompactElems);
     else
-        hipLaunchKernelGGL(k_sw_trace_wave, dim3(n), dim3(64), 0, s, c->d_jobs.p, n, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
+        hipLaunchKernelGGL(k_sw_trace_wave, dim3(n_jobs), dim3(64), 0, s, c->d_jobs.p, n_jobs, c->d_bt.p, c->d_sc.p, c->d_el.p, c->d_res.p,
                            c->d_cel.p, kCompactElems);
     HIP_TRY(hipEventRecord(c->ev[2], s));
     HIP_TRY(hipGetLastError());
+    tp[3] = now();
     std::vector<SwResult> res(n);
     std::unique_ptr<int16_t[]> cel(new (std::nothrow) int16_t[(size_t)n * 2 * kCompactElems]);
     if (!cel) return -ENOMEM;
@@ -581,6 +927,7 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
     c->stats.backtrace_bytes += bt;
     // results and CIGAR text, a few threads when the batch is large (rendering long element lists is
     // the library's biggest host cost)
+    tp[4] = now();
     auto emit = [&](u32 q0, u32 q1, u64* cells_out) {
         u64 cells = 0;
         for (u32 q = q0; q < q1; ++q) {
@@ -611,6 +958,9 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         for (auto& t : th) t.join();
     }
     for (u64 x : cells) c->stats.cells += x;
+    tp[5] = now();
+    if (prof) fprintf(stderr, "[mgx_sw] %u pairs: jobs %.3f  stage+H2D %.3f  launches %.3f  kernels+D2H %.3f  text %.3f ms\n", n, tp[1] - tp[0], tp[2] - tp[1],
+                      tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4]);
     return 0;
 }
 
@@ -674,7 +1024,8 @@ static int align_impl(mgx_sw_t* c, const mgx_sw_params_t* params, const mgx_sw_i
         u64 hi = lo, bt = 0;
         while (hi < in->n_pairs) {
             const u64 l1 = in->ref_off[hi + 1] - in->ref_off[hi], l2 = in->alt_off[hi + 1] - in->alt_off[hi];
-            const u64 need = bt_bytes(l1, l2, shape_for((int)l1, false)) + 16;     // the one-pair shape is the larger of the two
+            const u64 need = std::max(bt_bytes(l1, l2, shape_for((int)l1, (int)l2, false)), bt_bytes(l1, l2, shape_for((int)l1, (int)l2, true))) + 16 +
+                             2 * lr_bytes16(l2, shape16_for((int)l1, true)) + 8 * (l1 + 64);
             if (hi > lo && bt + need > limit) break;
             bt += need; ++hi;
         }

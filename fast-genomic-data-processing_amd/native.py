@@ -171,7 +171,7 @@ class SwInput(C.Structure):
 
 class SwStats(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("cells", C.c_uint64), ("n_launches", C.c_uint32), ("ms_fill", C.c_float),
-                ("ms_trace", C.c_float), ("backtrace_bytes", C.c_uint64)]
+                ("ms_trace", C.c_float), ("backtrace_bytes", C.c_uint64), ("n_pairs_i16", C.c_uint64)]
 
 
 SMITHWATERMAN_SYMBOLS = {

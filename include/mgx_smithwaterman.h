@@ -59,9 +59,10 @@ typedef struct mgx_sw_input {
 
 typedef struct mgx_sw_stats {
     uint64_t n_pairs, cells;         /* cells = sum of refLength * altLength */
-    uint32_t n_launches;             /* fill-kernel launches of the last batch (one per row class) */
+    uint32_t n_launches;             /* fill-kernel launches of the last batch */
     float ms_fill, ms_trace;         /* HIP events around the matrix fill and the back-trace kernels */
     uint64_t backtrace_bytes;        /* back-trace arena written by the fill kernels */
+    uint64_t n_pairs_i16;            /* pairs whose scores provably fit 16 bits: filled two to a lane group with packed arithmetic */
 } mgx_sw_stats_t;
 
 int mgx_sw_create(int device, unsigned flags, mgx_sw_t** out);
