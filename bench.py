@@ -34,7 +34,7 @@ PKG = "fast-genomic-data-processing_amd"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 VALU_INT32_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # one int32 lane-operation per lane per clock: 78.6 T lane-op/s
-SW_INSTR_PER_CELL = 32         # k_sw_fill as compiled
+SW_INSTR_PER_CELL = 12.7       # k_sw_fill16 as compiled: 279 VALU instructions per step of 11 rows x 2 pairs
 
 
 def host_cores():
@@ -234,17 +234,20 @@ def smithwaterman_leg(pkg, synth, args, rank, local_rank):
         st = eng.stats(); fills.append(st["ms_fill"]); traces.append(st["ms_trace"])
     ms_fill, ms_trace = float(np.median(fills)), float(np.median(traces))
     out = {"metric": "Smith-Waterman GCUPS (matrix fill + back-trace on the device, inputs resident)",
-           "value": st["cells"] / (ms_fill + ms_trace) / 1e6, "unit": "GCUPS", "dtype": "i32",
+           "value": st["cells"] / (ms_fill + ms_trace) / 1e6, "unit": "GCUPS", "dtype": "i16 (packed; i32 for pairs whose scores may not fit)",
+           "pairs_on_the_16_bit_kernel": st["n_pairs_i16"],
            "config": {"workload": "synthetic reads (100-151 bases) against haplotype windows (250-400 bases), STANDARD_NGS "
                                   "parameters, SOFTCLIP", "pairs": n, "cells": st["cells"]},
            "ms_fill": ms_fill, "ms_trace": ms_trace, "backtrace_bytes": st["backtrace_bytes"],
            "roofline": {"bound": "valu", "achieved": st["cells"] * SW_INSTR_PER_CELL / (ms_fill * 1e-3) / 1e12, "peak": VALU_INT32_PEAK_TOPS,
                         "unit": "T lane-op/s", "frac": st["cells"] * SW_INSTR_PER_CELL / (ms_fill * 1e-3) / 1e12 / VALU_INT32_PEAK_TOPS, "traffic": None,
-                        "kernel": "k_sw_fill<8>", "kernel_ms": ms_fill,
-                        "hbm": {"achieved": st["cells"] / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": st["cells"] / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "1 algorithmic byte per cell (the back-trace byte)"},
-                        "note": "the fill is int32-VALU bound: 32 instructions per cell as compiled (DESIGN.md 4b) against 256 CUs x 4 SIMDs x 32 lanes x "
-                                "2.4 GHz = 78.6 T lane-op/s; 64 % of the lanes and 76 % of the anti-diagonal steps are busy at this shape; the trace is a latency chain"}}
+                        "kernel": "k_sw_fill16<32,false>", "kernel_ms": ms_fill,
+                        "hbm": {"achieved": 0.5 * st["cells"] / (ms_fill * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": 0.5 * st["cells"] / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "half an algorithmic byte per cell (the back-trace nibble)",
+                                "written": st["backtrace_bytes"]},
+                        "note": "the fill is integer-VALU bound: 12.7 instructions per cell as compiled (25 packed 16-bit instructions per two cells, "
+                                "DESIGN.md 4b) against 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-op/s; padding rows, fill/drain steps and "
+                                "the longer partner of a lane group keep ~60 % of the cell slots busy at this shape; the trace is a latency chain"}}
     if not args.no_cpu_baseline:
         so = os.path.join(ROOT, "oracle", "_ref", "libref_smithwaterman.so")
         if os.path.exists(so):

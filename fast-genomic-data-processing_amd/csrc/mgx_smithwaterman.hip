@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64) void k_sw_fill(const SwJob* __restrict__ jobs, 
 // and the four decisions of a cell -- E opened, F opened, E beats the diagonal, F beats both -- are the SIGN BITS of four packed
 // differences, merged with v_bfi into one nibble per pair: ~25 instructions per two cells.  Values are the reference's exactly as long
 // as nothing wraps: the host admits a pair only when every real value and every difference of two of them fits 16 bits
-// (fits_i16 below: bounds from the lengths and the scoring parameters; LOW_INIT_VALUE becomes a per-pair value below every real one),
+// (I16Rule below: bounds from the lengths and the scoring parameters; LOW_INIT_VALUE becomes a per-pair value below every real one),
 // everything else takes k_sw_fill.  Cells outside a pair's own matrix (the other half is longer, padding rows) may wrap: nothing real
 // reads them.
 //   * back-trace: one 32-bit word per lane, step and four rows: low half = the first pair's four nibbles (row 4q in bits 0-3),
@@ -586,10 +586,8 @@ struct Shape { int g, rpl; bool tr; };
 // wavefront (32 lanes x 1..8) whenever the batch is large enough to fill the device that way; otherwise, and beyond, one pair
 // per wavefront (64 lanes x 1..32) so that every SIMD still has several wavefronts to hide the dependent integer chain of a
 // step behind.  MGX_SW_TRANSPOSE=0 keeps the lanes on the reference (round 2's shapes; A/B and tests).
-Shape shape_for(int len1, int len2, bool paired) {
-    const char* e_tr = getenv("MGX_SW_TRANSPOSE");
-    const int transpose = e_tr ? atoi(e_tr) : 0;
-    const bool tr = transpose != 0 && len2 < len1;
+Shape shape_for(int len1, int len2, bool paired, bool transpose) {
+    const bool tr = transpose && len2 < len1;
     const int n_own = tr ? len2 : len1;
     if (paired) {
         static const int cls32[] = {1, 2, 3, 4, 5, 6, 7, 8, 12, 16};
@@ -599,6 +597,19 @@ Shape shape_for(int len1, int len2, bool paired) {
     for (int r : cls64) if (n_own <= 64 * r) return Shape{64, r, tr};
     return Shape{0, 0, false};
 }
+// knobs of one call, read from the environment once (tests and A/B runs set them between calls)
+struct Knobs {
+    int paired = -1;          // MGX_SW_PAIRED: force two lane groups per wavefront (1) or one (0)
+    bool use16 = true;        // MGX_SW_I16=0: the 32-bit fill for every pair
+    bool transpose = false;   // MGX_SW_TRANSPOSE=1: 32-bit fill with the lanes over the shorter sequence
+    u64 arena = 0;            // MGX_SW_ARENA_LIMIT
+    Knobs() {
+        if (const char* e = getenv("MGX_SW_PAIRED")) paired = atoi(e) != 0;
+        if (const char* e = getenv("MGX_SW_I16")) use16 = atoi(e) != 0;
+        if (const char* e = getenv("MGX_SW_TRANSPOSE")) transpose = atoi(e) != 0;
+        if (const char* e = getenv("MGX_SW_ARENA_LIMIT")) { const long long v = atoll(e); if (v > 0) arena = (u64)v; }
+    }
+};
 constexpr u32 kPairedFrom = 8192;             // pairs in a chunk from which two lane groups share a wavefront (round 2: 32768)
 
 // ---- the packed 16-bit fill (k_sw_fill16): shapes and admission
@@ -614,23 +625,29 @@ Shape shape16_for(int len1, bool paired) {
 //   one more open / extend / match on top of either: `pad`
 // LOW_INIT_VALUE only ever meets a real value as LOW + extend against H + open (first column of E, first row of F) and must lose
 // strictly: low = L - |extend| - 1.  MATRIX_MIN_CUTOFF (-1e8) cannot bind inside 16 bits.
-bool fits_i16(int64_t n, int64_t m, const SwParams& P, int32_t* low16) {
-    if (m > 4096) return false;                          // two alternates per lane group are staged in LDS as 32-bit words
-    const int64_t mx = std::max(n, m), mn = std::min(n, m);
-    const int64_t dlo = std::min<int64_t>(P.match, P.mismatch), dhi = std::max<int64_t>(P.match, P.mismatch);
-    const int64_t b_end = (int64_t)P.open + (mx - 1) * (int64_t)P.extend;
-    const int64_t blo = std::min<int64_t>({0, P.open, b_end}), bhi = std::max<int64_t>({0, P.open, b_end});
-    const int64_t pos = std::max<int64_t>({dhi, P.open, P.extend, 0});
-    const int64_t u0 = (P.open <= 0 && P.extend <= 0) ? bhi + mn * std::max<int64_t>(dhi, 0) : bhi + (n + m) * pos;
-    const int64_t lh = blo + mn * std::min<int64_t>(dlo, 0);
-    const int64_t a_ext = std::llabs((long long)P.extend);
-    const int64_t pad = std::llabs((long long)P.open) + a_ext + std::max(std::llabs((long long)P.match), std::llabs((long long)P.mismatch));
-    const int64_t lo = lh - pad, up = u0 + pad;
-    const int64_t low = lo - a_ext - 1, ll = low - a_ext;
-    if (ll < -32768 || up > 32767 || up - ll > 32767) return false;
-    *low16 = (int32_t)low;
-    return true;
-}
+struct I16Rule {
+    int64_t open, extend, dlo, dhi, pos, a_ext, pad;
+    bool gaps_cost;
+    explicit I16Rule(const SwParams& P) : open(P.open), extend(P.extend), dlo(std::min(P.match, P.mismatch)), dhi(std::max(P.match, P.mismatch)) {
+        pos = std::max<int64_t>({dhi, open, extend, 0});
+        a_ext = std::llabs((long long)extend);
+        pad = std::llabs((long long)open) + a_ext + std::max(std::llabs((long long)P.match), std::llabs((long long)P.mismatch));
+        gaps_cost = open <= 0 && extend <= 0;
+    }
+    bool admits(int64_t n, int64_t m, int32_t* low16) const {
+        if (m > 4096) return false;                          // two alternates per lane group are staged in LDS as 32-bit words
+        const int64_t mx = std::max(n, m), mn = std::min(n, m);
+        const int64_t b_end = open + (mx - 1) * extend;
+        const int64_t blo = std::min<int64_t>({0, open, b_end}), bhi = std::max<int64_t>({0, open, b_end});
+        const int64_t u0 = gaps_cost ? bhi + mn * std::max<int64_t>(dhi, 0) : bhi + (n + m) * pos;
+        const int64_t lh = blo + mn * std::min<int64_t>(dlo, 0);
+        const int64_t lo = lh - pad, up = u0 + pad;
+        const int64_t low = lo - a_ext - 1, ll = low - a_ext;
+        if (ll < -32768 || up > 32767 || up - ll > 32767) return false;
+        *low16 = (int32_t)low;
+        return true;
+    }
+};
 inline u64 bt_bytes16(u64 steps_max, const Shape& sh) { return ((steps_max + 1) * sh.g * bt_slot16(sh.rpl) + 15) & ~15ull; }
 inline u64 lr_bytes16(u64 n_swp, const Shape& sh) { return ((n_swp + 1) * sh.rpl * 4 + 15) & ~15ull; }
 constexpr int kCompactElems = 16;             // merged CIGAR elements copied back per pair without a second look
@@ -691,6 +708,8 @@ struct mgx_sw {
     mgx_sw_stats_t stats{};
     void* pin = nullptr;          // pinned staging for the uploads (a pageable source is copied at a few GB/s)
     size_t pin_cap = 0;
+    void* pin_out = nullptr;      // pinned landing area of the results (a pageable target goes through the runtime's own staging)
+    size_t pin_out_cap = 0;
 };
 
 namespace {
@@ -709,44 +728,55 @@ void launch_fill(mgx_sw* c, const SwJob* jobs, u32 n, u32 max_swept, bool tr, Sw
 }
 
 // pairs [lo, hi) of the input, already validated
-int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in, u64 lo, u64 hi,
+int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in, u64 lo, u64 hi, const Knobs& knobs,
               int32_t* out_offset, char* out_cigar, u32 stride, int32_t* out_score, int cap_override) {
     const u32 n = (u32)(hi - lo);
     static const bool prof = [] { const char* e = getenv("MGX_SW_PROF"); return e && atoi(e) != 0; }();      // host stage times on stderr
     double tp[6] = {0};
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     tp[0] = now();
-    bool paired = n >= kPairedFrom;
-    if (const char* e = getenv("MGX_SW_PAIRED")) paired = atoi(e) != 0;      // tests: force either shape family
-    bool use16 = true;
-    if (const char* e = getenv("MGX_SW_I16")) use16 = atoi(e) != 0;          // 0: the 32-bit fill for every pair (A/B, tests)
+    const bool paired = knobs.paired >= 0 ? knobs.paired != 0 : n >= kPairedFrom;
     const SwParams P{params->match, params->mismatch, params->gap_open, params->gap_extend};
+    const I16Rule rule(P);
     const u64 base1 = in->ref_off[lo], base2 = in->alt_off[lo];
-    // jobs in input order first (score and element arenas are laid out in that order), then sorted into launch order:
-    // the packed 16-bit classes first (32 lanes, then 64; most rows per lane first), the 32-bit classes after them,
-    // longest alternate first inside a class (the two pairs of a lane group and the groups of a wavefront finish together;
-    // a launch drains on its cheapest jobs).  Two counting sorts: a comparison sort of 10^5 jobs costs more than their alignments.
-    std::vector<SwJob> pre(n);
-    std::vector<uint16_t> cls(n);
-    u64 scn = 0, eln = 0;
+    const u64 n1 = in->ref_off[hi] - base1, n2 = in->alt_off[hi] - base2;
+    // the sequences travel to pinned memory on a helper thread while this one lays out the jobs
+    const u32 max_jobs = n + 256;                        // fillers: at most 3 per 16-bit class
+    const size_t a1 = (n1 + 255) & ~(size_t)255, a2 = (n2 + 255) & ~(size_t)255, total = a1 + a2 + max_jobs * sizeof(SwJob);
+    if (total > c->pin_cap) {
+        if (c->pin) (void)hipHostFree(c->pin);
+        c->pin = nullptr; c->pin_cap = 0;
+        HIP_TRY(hipHostMalloc(&c->pin, total + total / 4, hipHostMallocDefault));
+        c->pin_cap = total + total / 4;
+    }
+    char* const pin = static_cast<char*>(c->pin);
+    std::thread stager[2];
+    struct Joiner { std::thread* t; ~Joiner() { for (int k = 0; k < 2; ++k) if (t[k].joinable()) t[k].join(); } } joiner{stager};
+    if (n1 + n2 >= (1u << 20)) {
+        stager[0] = std::thread([=] { memcpy(pin, in->ref + base1, n1); });
+        stager[1] = std::thread([=] { memcpy(pin + a1, in->alt + base2, n2); });
+    } else { memcpy(pin, in->ref + base1, n1); memcpy(pin + a1, in->alt + base2, n2); }
+    // Per pair in input order: class and admission.  Then launch order: the packed 16-bit classes first (32 lanes, then 64; most
+    // rows per lane first), the 32-bit classes after them, longest alternate first inside a class (the two pairs of a lane group
+    // and the groups of a wavefront finish together; a launch drains on its cheapest jobs).  Two counting sorts: a comparison sort
+    // of 10^5 jobs costs more than their alignments.  The score and element arenas are laid out in input order: pair q's score
+    // rows start at (bases before it) + 2 q.
+    struct Pre { u32 len1, len2; int32_t low16; uint16_t cls; uint8_t rpl, g; };
+    std::vector<Pre> pre(n);
     for (u32 q = 0; q < n; ++q) {
         const u64 p = lo + q;
-        SwJob& J = pre[q];
-        J = SwJob{};
-        J.off1 = in->ref_off[p] - base1; J.off2 = in->alt_off[p] - base2;
+        Pre& J = pre[q];
         J.len1 = (u32)(in->ref_off[p + 1] - in->ref_off[p]); J.len2 = (u32)(in->alt_off[p + 1] - in->alt_off[p]);
-        J.strategy = in->strategy[p]; J.out_index = q;
-        J.sc_off = scn; scn += (u64)J.len1 + J.len2 + 2;
-        J.el_off = eln; eln += 2 * ((u64)J.len1 + J.len2 + 2);
-        if (use16 && fits_i16(J.len1, J.len2, P, &J.low16)) {
+        J.low16 = 0;
+        if (knobs.use16 && rule.admits(J.len1, J.len2, &J.low16)) {
             const Shape sh = shape16_for((int)J.len1, paired);
-            J.rpl = (u32)sh.rpl; J.g = (u32)sh.g | kJobI16;
-            cls[q] = (uint16_t)((sh.g == 64 ? 64 : 0) + (32 - sh.rpl));                                  // < 128
+            J.rpl = (uint8_t)sh.rpl; J.g = (uint8_t)sh.g;
+            J.cls = (uint16_t)((sh.g == 64 ? 64 : 0) + (32 - sh.rpl));                                  // < 128
             c->stats.n_pairs_i16++;
         } else {
-            const Shape sh = shape_for((int)J.len1, (int)J.len2, paired);
-            J.rpl = (u32)sh.rpl; J.g = (u32)sh.g | (sh.tr ? kJobTr : 0u);
-            cls[q] = (uint16_t)(128 + (sh.g == 64 ? 64 : 0) + (sh.tr ? 128 : 0) + sh.rpl);               // < 384
+            const Shape sh = shape_for((int)J.len1, (int)J.len2, paired, knobs.transpose);
+            J.rpl = (uint8_t)sh.rpl; J.g = (uint8_t)sh.g;
+            J.cls = (uint16_t)(128 + (sh.g == 64 ? 64 : 0) + (sh.tr ? 128 : 0) + sh.rpl);               // < 384
         }
     }
     std::vector<u32> order(n);
@@ -756,25 +786,36 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         for (u32 k = 0; k < 32768; ++k) cnt[k + 1] += cnt[k];
         for (u32 q = 0; q < n; ++q) tmp[cnt[32767 - pre[q].len2]++] = q;
         u32 c2[385] = {0};
-        for (u32 q = 0; q < n; ++q) c2[cls[q] + 1]++;
+        for (u32 q = 0; q < n; ++q) c2[pre[q].cls + 1]++;
         for (int k = 0; k < 384; ++k) c2[k + 1] += c2[k];
-        for (u32 x = 0; x < n; ++x) order[c2[cls[tmp[x]]]++] = tmp[x];
+        for (u32 x = 0; x < n; ++x) order[c2[pre[tmp[x]].cls]++] = tmp[x];
     }
-    std::vector<SwJob> jobs;
-    jobs.reserve(n + 64);
+    SwJob* const jobs = reinterpret_cast<SwJob*>(pin + a1 + a2);             // built in place, in launch order
+    u32 n_jobs = 0;
+    auto make_job = [&](u32 q) {
+        const u64 p = lo + q;
+        const Pre& R = pre[q];
+        SwJob J{};
+        J.off1 = in->ref_off[p] - base1; J.off2 = in->alt_off[p] - base2;
+        J.len1 = R.len1; J.len2 = R.len2; J.rpl = R.rpl; J.strategy = in->strategy[p]; J.out_index = q;
+        J.sc_off = J.off1 + J.off2 + 2ull * q; J.el_off = 2 * J.sc_off;
+        J.low16 = R.low16;
+        J.g = (u32)R.g | (R.cls < 128 ? kJobI16 : (R.cls >= 256 ? kJobTr : 0u));
+        return J;
+    };
     u64 bt = 0;
     for (u32 x = 0; x < n;) {
         const u32 q0 = order[x];
-        if (pre[q0].g & kJobI16) {
+        if (pre[q0].cls < 128) {
             // one class: lane groups of two pairs, whole wavefronts
-            const u32 c = cls[q0];
-            const Shape sh{(int)(pre[q0].g & 0xFFu), (int)pre[q0].rpl, false};
+            const u32 cl = pre[q0].cls;
+            const Shape sh{(int)pre[q0].g, (int)pre[q0].rpl, false};
             const u32 per_wave = 2 * (64 / sh.g);
             u32 y = x;
-            while (y < n && cls[order[y]] == c) ++y;
+            while (y < n && pre[order[y]].cls == cl) ++y;
             for (u32 z = x; z < y; z += 2) {
-                SwJob A = pre[order[z]], B{};
-                if (z + 1 < y) B = pre[order[z + 1]];
+                SwJob A = make_job(order[z]), B{};
+                if (z + 1 < y) B = make_job(order[z + 1]);
                 else { B.out_index = kNoOutput; B.rpl = A.rpl; B.g = A.g; }
                 B.g |= kJobHalf;
                 auto lanes = [&](const SwJob& j) { return (u64)(j.len1 + sh.rpl - 1) / sh.rpl; };
@@ -788,52 +829,32 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
                 A.lc_off = bt; bt += lc_bytes;
                 if (B.len2 == A.len2 || B.len1 == 0) B.lc_off = A.lc_off;
                 else { B.lc_off = bt; bt += lc_bytes; }
-                jobs.push_back(A); jobs.push_back(B);
+                jobs[n_jobs++] = A; jobs[n_jobs++] = B;
             }
-            while (jobs.size() % per_wave) {                 // filler groups up to the wavefront boundary
-                SwJob F{}; F.out_index = kNoOutput; F.rpl = (u32)sh.rpl; F.g = (u32)sh.g | kJobI16 | (jobs.size() % 2 ? kJobHalf : 0u);
-                jobs.push_back(F);
+            while (n_jobs % per_wave) {                      // filler groups up to the wavefront boundary
+                SwJob F{}; F.out_index = kNoOutput; F.rpl = (u32)sh.rpl; F.g = (u32)sh.g | kJobI16 | (n_jobs % 2 ? kJobHalf : 0u);
+                jobs[n_jobs++] = F;
             }
             x = y;
         } else {
-            SwJob J = pre[q0];
+            SwJob J = make_job(q0);
             const Shape sh{(int)(J.g & 0xFFu), (int)J.rpl, (J.g & kJobTr) != 0};
             J.bt_off = bt; bt += bt_bytes(J.len1, J.len2, sh);
-            jobs.push_back(J);
+            jobs[n_jobs++] = J;
             ++x;
         }
     }
-    const u32 n_jobs = (u32)jobs.size();
+    const u64 scn = n1 + n2 + 2ull * n, eln = 2 * scn;
     tp[1] = now();
-    const u64 n1 = in->ref_off[hi] - base1, n2 = in->alt_off[hi] - base2;
     int rc;
     if ((rc = c->d_s1.reserve(n1 + 16)) || (rc = c->d_s2.reserve(n2 + 16)) || (rc = c->d_bt.reserve(bt + 16)) || (rc = c->d_jobs.reserve(n_jobs)) ||
         (rc = c->d_sc.reserve(scn)) || (rc = c->d_el.reserve(eln)) || (rc = c->d_res.reserve(n)) ||
         (rc = c->d_cel.reserve((size_t)n * 2 * kCompactElems))) return rc;
     hipStream_t s = c->stream;
-    {
-        const size_t a1 = (n1 + 255) & ~(size_t)255, a2 = (n2 + 255) & ~(size_t)255, total = a1 + a2 + n_jobs * sizeof(SwJob);
-        if (total > c->pin_cap) {
-            if (c->pin) (void)hipHostFree(c->pin);
-            c->pin = nullptr; c->pin_cap = 0;
-            HIP_TRY(hipHostMalloc(&c->pin, total + total / 4, hipHostMallocDefault));
-            c->pin_cap = total + total / 4;
-        }
-        char* pin = static_cast<char*>(c->pin);
-        const char* src[3] = {reinterpret_cast<const char*>(in->ref + base1), reinterpret_cast<const char*>(in->alt + base2),
-                              reinterpret_cast<const char*>(jobs.data())};
-        char* dst[3] = {pin, pin + a1, pin + a1 + a2};
-        const size_t len[3] = {(size_t)n1, (size_t)n2, n_jobs * sizeof(SwJob)};
-        if (total < (8u << 20)) { for (int k = 0; k < 3; ++k) memcpy(dst[k], src[k], len[k]); }
-        else {
-            std::thread th[3];
-            for (int k = 0; k < 3; ++k) th[k] = std::thread([=] { memcpy(dst[k], src[k], len[k]); });
-            for (auto& t : th) t.join();
-        }
-        HIP_TRY(hipMemcpyAsync(c->d_s1.p, dst[0], n1, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->d_s2.p, dst[1], n2, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(c->d_jobs.p, dst[2], n_jobs * sizeof(SwJob), hipMemcpyHostToDevice, s));
-    }
+    for (auto& t : stager) if (t.joinable()) t.join();
+    HIP_TRY(hipMemcpyAsync(c->d_s1.p, pin, n1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_s2.p, pin + a1, n2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_jobs.p, jobs, n_jobs * sizeof(SwJob), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(c->ev[0], s));
     tp[2] = now();
     for (u32 a = 0; a < n_jobs;) {
@@ -887,11 +908,18 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
     HIP_TRY(hipEventRecord(c->ev[2], s));
     HIP_TRY(hipGetLastError());
     tp[3] = now();
-    std::vector<SwResult> res(n);
-    std::unique_ptr<int16_t[]> cel(new (std::nothrow) int16_t[(size_t)n * 2 * kCompactElems]);
-    if (!cel) return -ENOMEM;
-    HIP_TRY(hipMemcpyAsync(res.data(), c->d_res.p, n * sizeof(SwResult), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(cel.get(), c->d_cel.p, (size_t)n * 2 * kCompactElems * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    const size_t res_bytes = ((size_t)n * sizeof(SwResult) + 63) & ~(size_t)63, cel_bytes = (size_t)n * 2 * kCompactElems * sizeof(int16_t);
+    if (res_bytes + cel_bytes > c->pin_out_cap) {
+        if (c->pin_out) (void)hipHostFree(c->pin_out);
+        c->pin_out = nullptr; c->pin_out_cap = 0;
+        const size_t want = (res_bytes + cel_bytes) * 5 / 4;
+        HIP_TRY(hipHostMalloc(&c->pin_out, want, hipHostMallocDefault));
+        c->pin_out_cap = want;
+    }
+    SwResult* const res = static_cast<SwResult*>(c->pin_out);
+    int16_t* const cel = reinterpret_cast<int16_t*>(static_cast<char*>(c->pin_out) + res_bytes);
+    HIP_TRY(hipMemcpyAsync(res, c->d_res.p, n * sizeof(SwResult), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cel, c->d_cel.p, cel_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     // alignments with more elements than the fixed record holds: one gather launch, one more download
     std::vector<GatherRef> big_refs;
@@ -940,7 +968,7 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
                 char* dst = out_cigar + (size_t)p * stride;
                 const int cap = cap_override >= 0 ? cap_override
                                                   : (int)std::min<u64>(2ull * std::max(l1, l2), (u64)stride - 1);   // IntelSmithWaterman.cpp:8
-                const int16_t* src = cel.get() + (size_t)q * 2 * kCompactElems;
+                const int16_t* src = cel + (size_t)q * 2 * kCompactElems;
                 if (r.n_elems > kCompactElems) src = big.get() + big_at[q];
                 const int len = render(src, r.n_elems, dst, cap);
                 dst[len] = 0;                             // cap <= stride - 1
@@ -995,6 +1023,7 @@ void mgx_sw_destroy(mgx_sw_t* c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
     delete c;
 }
 
@@ -1017,19 +1046,22 @@ static int align_impl(mgx_sw_t* c, const mgx_sw_params_t* params, const mgx_sw_i
         if (st < MGX_SW_SOFTCLIP || st > MGX_SW_IGNORE) { set_error("pair %llu: unknown overhang strategy %d", (unsigned long long)p, st); return -EINVAL; }
     }
     HIP_TRY(hipSetDevice(c->device));
-    u64 limit = kArenaLimit;
-    if (const char* e = getenv("MGX_SW_ARENA_LIMIT")) { const long long v = atoll(e); if (v > 0) limit = (u64)v; }
+    const Knobs knobs;
+    const u64 limit = knobs.arena ? knobs.arena : kArenaLimit;
     u64 lo = 0;
     while (lo < in->n_pairs) {
         u64 hi = lo, bt = 0;
         while (hi < in->n_pairs) {
+            // an upper bound of what the pair takes of the back-trace arena in any shape: the one-pair-per-wavefront 32-bit form
+            // (the paired form and the 16-bit form are smaller) plus the 16-bit kernel's edge rows
             const u64 l1 = in->ref_off[hi + 1] - in->ref_off[hi], l2 = in->alt_off[hi + 1] - in->alt_off[hi];
-            const u64 need = std::max(bt_bytes(l1, l2, shape_for((int)l1, (int)l2, false)), bt_bytes(l1, l2, shape_for((int)l1, (int)l2, true))) + 16 +
-                             2 * lr_bytes16(l2, shape16_for((int)l1, true)) + 8 * (l1 + 64);
+            const u64 rows = (l1 + 63) / 64, slot = rows <= 8 ? ((rows + 3) & ~3ull) : rows <= 16 ? 16 : 32;
+            const u64 swept = knobs.transpose ? std::max(l1, l2) : l2;
+            const u64 need = (swept + 64 + 1) * 64 * slot + 8 * (l2 + 1) * ((l1 + 31) / 32 * 3 / 2 + 2) + 8 * (l1 + 64) + 64;
             if (hi > lo && bt + need > limit) break;
             bt += need; ++hi;
         }
-        const int rc = run_chunk(c, params, in, lo, hi, out_offset, out_cigar, cigar_stride, out_score, cap_override);
+        const int rc = run_chunk(c, params, in, lo, hi, knobs, out_offset, out_cigar, cigar_stride, out_score, cap_override);
         if (rc) return rc;
         lo = hi;
     }
