@@ -476,13 +476,16 @@ def mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_ove
     n_local = min(hi - lo, 4 << 20)                    # a window of the rank's shard keeps the leg short
     d = synth.gen_pairhmm_pairs_fast(n_local, 0x5EED0003, first_pair=lo, threads=host_threads(world))
     prepared = pkg.pairhmm.make_input(d)
-    lanes = args.queue_lanes or max(2, min(8, host_cores() // world))
+    # four lanes keep the link as busy as eight (the queue is PCIe-bound) and leave the 4 x 3 PairHMM streams and the sort's 4 one
+    # hardware queue each out of GPU_MAX_HW_QUEUES=16: streams that share a hardware queue serialise (sort 2 200 -> 4 900 Mrecords/s)
+    lanes = args.queue_lanes or max(2, min(4, host_cores() // world))
     q = pkg.PairHMMQueue(devices=(local_rank,), lanes_per_device=lanes, depth=2, batch_pairs=65536)
     # "interleave config-3 batches with 8 coordinate-range shards of config 4": a GPU's share of
     # the record set is one eighth of configs[3] (25 M records), whatever the number of ranks of THIS run
     n_rec = max(args.sort_records // max(world, 8), 1_000_000) if args.sort_records else 25_000_000
     recs, L = synth.gen_sortdedup_packed_fast(n_rec, 0x5EED0004 + rank, threads=host_threads(world))
-    eng = pkg.SortDedupEngine(local_rank)
+    sort_flags = int(os.environ.get("MGX_MIXED_SORT_FLAGS", str(1 << 16)), 0)      # MGX_STREAM_HIGH_PRIORITY (A/B: 0)
+    eng = pkg.SortDedupEngine(local_rank, flags=sort_flags)
     eng.upload(L, recs)
     q.run(d, lo=0, hi=min(n_local, lanes * 2 * 65536), prepared=prepared); eng.run(); eng.stats()
 
@@ -517,6 +520,7 @@ def mixed_leg(pkg, synth, args, rank, local_rank, world, shard, barrier, max_ove
             "pairhmm_queue_gcups": {"alone": hmm_alone, "mixed": hmm_mixed}, "sortmardup_mrecords_s": {"alone": sort_alone, "mixed": sort_mixed},
             "combined_utilisation": hmm_mixed / max(hmm_alone, 1e-9) + sort_mixed / max(sort_alone, 1e-9),
             "config": {"pairs_per_gpu_window": n_local, "records_per_gpu": len(recs), "queue_lanes": lanes,
+                       "sort_streams": "highest priority (MGX_STREAM_HIGH_PRIORITY)" if sort_flags & (1 << 16) else "default priority",
                        "window_s": {"alone": args.mixed_seconds, "mixed": 2 * args.mixed_seconds}},
             "note": "two host threads per GPU, separate contexts and streams; PairHMM streamed from host memory through the work queue, "
                     "sort records resident (independent per-GPU record sets in this leg)"}

@@ -1392,6 +1392,13 @@ int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
+    // MGX_STREAM_HIGH_PRIORITY (bit 16): the pipeline's short HBM-bound kernels go ahead of a co-resident PairHMM context's
+    int prio_least = 0, prio_greatest = 0;
+    const bool high = (flags & (1u << 16)) != 0;
+    if (high) HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    auto make_stream = [&](hipStream_t* st) {
+        return high ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_greatest) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
     {
         // optional CU partition (flags bits 8..15: an 8-bit pattern repeated over the CU index): lets a
         // VALU-bound PairHMM context and an HBM-bound sort context share one GPU side by side instead
@@ -1403,12 +1410,12 @@ int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out) {
             for (int cu = 0; cu < c->n_cu; ++cu) if ((pat >> (cu & 7)) & 1u) mask[cu >> 5] |= 1u << (cu & 31);
             HIP_TRY(hipExtStreamCreateWithCUMask(&c->compute, (uint32_t)n_words, mask.data()));
         } else {
-            HIP_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
+            HIP_TRY(make_stream(&c->compute));
         }
     }
-    HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    HIP_TRY(make_stream(&c->copy));
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIP_TRY(make_stream(&c->side[i]));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_ind, hipEventDisableTiming));

@@ -57,6 +57,10 @@ typedef struct mgx_pairhmm_batch mgx_pairhmm_batch_t;
 /* bits 8..15 (both mgx_pairhmm_create and mgx_sortdedup_create): optional CU partition, an 8-bit
  * pattern repeated over the CU index; 0 or 0xFF = all CUs.  MGX_CU_PATTERN(0x3F) keeps 6 CUs of 8. */
 #define MGX_CU_PATTERN(p) (((unsigned)(p) & 0xFFu) << 8)
+/* bit 16 (both create calls): the context's streams get the highest priority the device offers -- for the HBM-bound sort
+ * pipeline when it shares a GPU with PairHMM batches (BASELINE.json configs[4]): its short kernels then take the compute units
+ * PairHMM workgroups free every ~20 us instead of queueing behind them.  Ignored together with a CU pattern. */
+#define MGX_STREAM_HIGH_PRIORITY (1u << 16)
 
 /* Packed host-side description of one batch of test cases. */
 typedef struct mgx_pairhmm_input {

@@ -90,6 +90,7 @@ typedef struct mgx_sortdedup_stats {
 int mgx_sortdedup_pack(const mgx_raw_records_t* raw, mgx_rec_t* out_recs, uint32_t* out_input_index,
                        uint64_t* out_L);
 
+/* flags: MGX_CU_PATTERN(p) and MGX_STREAM_HIGH_PRIORITY as for mgx_pairhmm_create (mgx_pairhmm.h), 0 otherwise */
 int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out);
 void mgx_sortdedup_destroy(mgx_sortdedup_t* ctx);
 
