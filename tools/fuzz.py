@@ -1,5 +1,5 @@
 """Randomised soak: loops over seeded random inputs for the paths and compares the device with the oracles
-(bit-exact for sort/dedup and Smith-Waterman, 1e-5 for PairHMM, zlib's inflate for the BGZF blocks).  usage: fuzz.py [seconds] [seed0]"""
+(bit-exact for sort/dedup and Smith-Waterman, 1e-5 for PairHMM, zlib's inflate for the BGZF blocks).  usage: fuzz.py [seconds] [seed0] [kind 0..6: that path only; 3 = Smith-Waterman]"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,7 @@ from conftest import PairHMMOracle, SortDedupOracle, SmithWatermanOracle, _ensur
 from test_pairhmm_gpu import flush_regime_pairs
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 ph, sd, sw = pkg.PairHMMEngine(0), pkg.SortDedupEngine(0), pkg.SmithWatermanEngine(0)
 oph, osd, osw = PairHMMOracle(_ensure_oracle()), SortDedupOracle(), SmithWatermanOracle()
 rng = np.random.default_rng(seed0)
@@ -20,7 +21,7 @@ bam_bytes = synth.gen_bam_record_bytes(6_000_000, 99, qual_bins=(2, 11, 25, 37))
 queue = pkg.PairHMMQueue(devices=(0, 0), lanes_per_device=2, depth=2, batch_pairs=700)
 while time.time() - t0 < budget:
     seed = int(rng.integers(1, 2**31 - 1)); it += 1
-    kind = it % 7
+    kind = only if only >= 0 else it % 7
     try:
         if kind == 0:
             kw = dict(n_contigs=int(rng.integers(1, 6)), contig_len=int(rng.choice([5000, 60000, 400000, 3000000])),
@@ -115,8 +116,12 @@ while time.time() - t0 < budget:
             counts["queue"] += 1
         else:
             os.environ["MGX_SW_PAIRED"] = str(rng.choice(["0", "1"]))
+            os.environ["MGX_SW_I16"] = str(rng.choice(["0", "1", "1", "1"]))          # the packed 16-bit fill (round 3) or the 32-bit one for every pair
+            os.environ["MGX_SW_TRANSPOSE"] = str(rng.choice(["0", "0", "1"]))
             w = synth.gen_sw_pairs(int(rng.integers(1, 400)), seed, ref_range=(1, int(rng.choice([60, 300, 700, 2048]))), alt_range=(1, int(rng.choice([40, 200, 600]))))
             params = tuple(int(x) for x in rng.choice([[25, -50, -110, -6], [3, -1, -4, -3], [1, -2, -3, -1], [10, -15, -30, -5]]))
+            if rng.integers(0, 3) == 0:         # anything: the 16-bit admission rule decides pair by pair
+                params = (int(rng.integers(1, 80)), -int(rng.integers(0, 160)), -int(rng.integers(0, 300)), -int(rng.integers(0, 50)))
             wc, wo, ws = osw.batch(w, params)
             gc, go, gs = sw.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"], params, want_score=True)
             ok = gc == wc and np.array_equal(go, wo) and np.array_equal(gs, ws)
