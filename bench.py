@@ -246,7 +246,8 @@ def smithwaterman_leg(pkg, synth, args, rank, local_rank):
                                 "frac": 0.5 * st["cells"] / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBS, "note": "half an algorithmic byte per cell (the back-trace nibble)",
                                 "written": st["backtrace_bytes"]},
                         "note": "the fill is integer-VALU bound: 12.7 instructions per cell as compiled (25 packed 16-bit instructions per two cells, "
-                                "DESIGN.md 4b) against 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-op/s; padding rows, fill/drain steps and "
+                                "DESIGN.md 4b) against 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-op/s (the packed instructions issue at half that rate: "
+                                "SQ_INSTS_VALU 1.97e8 per launch = 3.2 cycles per instruction, profiles/pmc_traffic.json); padding rows, fill/drain steps and "
                                 "the longer partner of a lane group keep ~60 % of the cell slots busy at this shape; the trace is a latency chain"}}
     if not args.no_cpu_baseline:
         so = os.path.join(ROOT, "oracle", "_ref", "libref_smithwaterman.so")

@@ -12,7 +12,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- python3 "$REPO/bench.py" --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err" || echo "stats run failed"
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   sub=pmc_$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//; s/sq_insts_valu/sq/')
-  rocprofv3 --pmc $c -d "$OUT/$sub" -o bench --output-format csv -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --sort-steps 1 --sw-pairs 0 --cli-records 0 --no-cpu-baseline --no-regions --no-queue --no-mixed > "$OUT/$sub.json" 2> "$OUT/$sub.err" || echo "$c run failed"
+  rocprofv3 --pmc $c -d "$OUT/$sub" -o bench --output-format csv -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --sort-steps 1 --cli-records 0 --no-cpu-baseline --no-regions --no-queue --no-mixed > "$OUT/$sub.json" 2> "$OUT/$sub.err" || echo "$c run failed"
 done
 cd "$REPO"
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
