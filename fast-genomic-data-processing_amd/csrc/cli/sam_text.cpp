@@ -5,6 +5,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace samtext {
 
@@ -66,13 +69,79 @@ const uint8_t* nt16_table() {
     return t;
 }
 
+// the first tab in [p, end), or end.  Most fields of a SAM line are a few bytes long: a call of memchr per field costs more than
+// the scan (round 3: the parse was ~180 ns of a record's ~700 ns on a parser thread)
+inline const char* find_tab(const char* p, const char* end) {
+#if defined(__SSE2__)
+    const __m128i tab = _mm_set1_epi8('\t');
+    while (p + 16 <= end) {
+        const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p)), tab));
+        if (m) return p + __builtin_ctz((unsigned)m);
+        p += 16;
+    }
+#endif
+    while (p < end && *p != '\t') ++p;
+    return p;
+}
+
 inline bool next_field(const char*& p, const char* end, const char** f, size_t* n) {
     if (p > end) return false;
-    const char* t = (const char*)memchr(p, '\t', (size_t)(end - p));
+    const char* t = find_tab(p, end);
     *f = p;
-    *n = t ? (size_t)(t - p) : (size_t)(end - p);
-    p = t ? t + 1 : end + 1;
+    *n = (size_t)(t - p);
+    p = t + 1;                                        // one past the tab, or end + 1 when the line ends here
     return true;
+}
+
+// 4-bit codes of l bases into (l + 1) / 2 bytes.  Sixteen bases at a time where they are all A C G T N (either case) and the CPU
+// has SSSE3: two table look-ups by the ASCII code's low nibble (the code, and the letter that nibble stands for, which must be
+// the base itself), then pairs folded with one multiply-add; anything else takes the 256-entry table, byte by byte.
+#if defined(__x86_64__)
+__attribute__((target("ssse3"))) size_t pack_bases_ssse3(const uint8_t* sq, size_t l, uint8_t* w) {
+    const __m128i code = _mm_setr_epi8(-1, 1, -1, 2, 8, -1, -1, 4, -1, -1, -1, -1, -1, -1, 15, -1);
+    const __m128i letter = _mm_setr_epi8(-1, 'A', -1, 'C', 'T', -1, -1, 'G', -1, -1, -1, -1, -1, -1, 'N', -1);
+    const __m128i low = _mm_set1_epi8(0x0F), upper = _mm_set1_epi8((char)0xDF), weight = _mm_set1_epi16(0x0110);
+    size_t i = 0;
+    for (; i + 16 <= l; i += 16) {
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(sq + i));
+        const __m128i nib = _mm_and_si128(b, low);
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_and_si128(b, upper), _mm_shuffle_epi8(letter, nib))) != 0xFFFF) break;
+        const __m128i pairs = _mm_maddubs_epi16(_mm_shuffle_epi8(code, nib), weight);          // code[2k] * 16 + code[2k + 1]
+        _mm_storel_epi64(reinterpret_cast<__m128i*>(w + i / 2), _mm_packus_epi16(pairs, pairs));
+    }
+    return i;                                         // bases done (a multiple of 16)
+}
+#endif
+inline void pack_bases(const uint8_t* sq, size_t l, uint8_t* w) {
+    size_t i = 0;
+#if defined(__x86_64__)
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
+    if (ssse3 && l >= 16) i = pack_bases_ssse3(sq, l, w);
+#endif
+    const uint8_t* nt16 = nt16_table();
+    size_t k = i / 2;
+    for (; 2 * k + 1 < l; ++k) w[k] = (uint8_t)(nt16[sq[2 * k]] << 4 | nt16[sq[2 * k + 1]]);
+    if (l & 1) w[k] = (uint8_t)(nt16[sq[l - 1]] << 4);
+}
+
+// phred values of l quality characters into q, and what BAMRecord::score makes of them (sortmardup/tbb/bam_record.cpp:7-14: the
+// sum of the values of at least 15 in a uint16_t, wrapping)
+inline uint16_t phred_and_score(const char* src, size_t l, uint8_t* q) {
+    size_t i = 0;
+    uint64_t sum = 0;
+#if defined(__SSE2__)
+    const __m128i off = _mm_set1_epi8(33), min15 = _mm_set1_epi8(15), zero = _mm_setzero_si128();
+    __m128i acc = zero;
+    for (; i + 16 <= l; i += 16) {
+        const __m128i v = _mm_sub_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i)), off);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(q + i), v);
+        const __m128i keep = _mm_cmpeq_epi8(_mm_max_epu8(v, min15), v);                        // v >= 15, unsigned
+        acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_and_si128(v, keep), zero));
+    }
+    sum = (uint64_t)_mm_cvtsi128_si64(acc) + (uint64_t)_mm_cvtsi128_si64(_mm_unpackhi_epi64(acc, acc));
+#endif
+    for (; i < l; ++i) { const uint8_t v = (uint8_t)(src[i] - 33); q[i] = v; sum += v >= 15 ? v : 0; }
+    return (uint16_t)sum;
 }
 
 // decimal integer with an optional sign, nothing else in the field (what strtoll accepts, minus leading blanks)
@@ -232,8 +301,8 @@ bool parse_record(const char* line, size_t len, const Header& h, Record* r, std:
 
 bool parse_record_into(const char* line, size_t len, const Header& h, Parsed* out, std::vector<uint32_t>* cigar, std::vector<uint8_t>* qual,
                        std::vector<char>* qname, std::vector<uint8_t>* blob, std::string* err) {
-    const size_t cigar0 = cigar->size(), qual0 = qual->size(), qname0 = qname->size(), blob0 = blob->size();
-    auto bad = [&](const char* why) { cigar->resize(cigar0); qual->resize(qual0); qname->resize(qname0); blob->resize(blob0); *err = why; return false; };
+    const size_t cigar0 = cigar->size(), qual0 = qual ? qual->size() : 0, qname0 = qname->size(), blob0 = blob->size();
+    auto bad = [&](const char* why) { cigar->resize(cigar0); if (qual) qual->resize(qual0); qname->resize(qname0); blob->resize(blob0); *err = why; return false; };
     const char* p = line; const char* end = line + len;
     const char* f[11]; size_t n[11];
     for (int k = 0; k < 11; ++k)
@@ -295,19 +364,14 @@ bool parse_record_into(const char* line, size_t len, const Header& h, Parsed* ou
     st(&tid, 4); st(&pos, 4); st(&lq, 1); st(&mapq, 1); st(&bin, 2); st(&nc, 2); st(&flag, 2); st(&l_seq_i, 4); st(&mtid, 4); st(&mpos, 4); st(&tlen, 4);
     st(f[0], n[0]); st(&zero, 1);
     if (n_cig) st(cigar->data() + cigar0, 4 * n_cig);
-    {
-        const uint8_t* nt16 = nt16_table();
-        const uint8_t* sq = (const uint8_t*)f[9];
-        size_t k = 0;
-        for (; 2 * k + 1 < l_seq; ++k) w[k] = (uint8_t)(nt16[sq[2 * k]] << 4 | nt16[sq[2 * k + 1]]);
-        if (l_seq & 1) w[k] = (uint8_t)(nt16[sq[l_seq - 1]] << 4);
-        w += n_seq4;
-    }
-    qual->resize(qual0 + l_seq);
-    uint8_t* q = qual->data() + qual0;
-    if (no_qual) { if (l_seq) memset(q, 0xFF, l_seq); }
-    else for (size_t i = 0; i < l_seq; ++i) q[i] = (uint8_t)(f[10][i] - 33);
-    st(q, l_seq);
+    pack_bases((const uint8_t*)f[9], l_seq, w);
+    w += n_seq4;
+    // qualities straight onto the record (and, for a caller that wants them apart, copied from there)
+    uint16_t score;
+    if (no_qual) { if (l_seq) memset(w, 0xFF, l_seq); score = (uint16_t)(255u * l_seq); }
+    else score = phred_and_score(f[10], l_seq, w);
+    if (qual) qual->insert(qual->end(), w, w + l_seq);
+    w += l_seq;
     qname->insert(qname->end(), f[0], f[0] + n[0]);
     // ---- the optional fields straight onto the record
     const char* af; size_t an;
@@ -315,7 +379,7 @@ bool parse_record_into(const char* line, size_t len, const Header& h, Parsed* ou
         if (an == 0) continue;
         if (!parse_aux(af, an, *blob, err)) { const std::string why = *err; return bad(why.c_str()); }
     }
-    out->flag = flag; out->tid = tid; out->pos = pos; out->end = rec_end;
+    out->flag = flag; out->tid = tid; out->pos = pos; out->end = rec_end; out->score = score;
     return true;
 }
 

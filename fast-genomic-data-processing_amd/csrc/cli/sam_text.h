@@ -42,10 +42,12 @@ bool parse_record(const char* line, size_t len, const Header& h, Record* out, st
 // What the sort / mark-duplicate key derivation and the index need of one record, next to its BAM bytes.
 struct Parsed {
     uint16_t flag; int32_t tid, pos, end;   // end: 0-based exclusive end on the reference (pos + 1 if no ref length)
+    uint16_t score;                         // BAMRecord::score (sortmardup/tbb/bam_record.cpp:7-14): qualities of at least 15, summed in 16 bits
 };
 // The same parse in one pass without a Record: the BAM encoding of the line (what bamout::encode_record makes of
 // parse_record's result, byte for byte) is APPENDED to *blob, its CIGAR operations / phred qualities / read name to
-// *cigar / *qual / *qname.  On failure nothing stays appended and *err says why.
+// *cigar / *qual / *qname (qual may be NULL: the qualities are on the record, and their score in *out).  On failure nothing stays
+// appended and *err says why.
 bool parse_record_into(const char* line, size_t len, const Header& h, Parsed* out, std::vector<uint32_t>* cigar, std::vector<uint8_t>* qual,
                        std::vector<char>* qname, std::vector<uint8_t>* blob, std::string* err);
 

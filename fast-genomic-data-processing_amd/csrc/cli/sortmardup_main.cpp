@@ -66,7 +66,7 @@ struct Slice { uint64_t seq = 0; std::string text; uint64_t file_off = 0; size_t
 struct Chunk {                       // one parsed + packed slice
     std::vector<uint16_t> flag; std::vector<int32_t> tid; std::vector<int64_t> pos; std::vector<int32_t> end;
     std::vector<uint32_t> cigar; std::vector<uint64_t> cigar_off{0};
-    std::vector<uint8_t> qual; std::vector<uint64_t> qual_off{0};
+    std::vector<uint16_t> score;                                        // BAMRecord::score per record, from the parser
     std::vector<char> qname; std::vector<uint64_t> qname_off{0};
     std::vector<uint8_t> blob; std::vector<uint64_t> blob_off{0};      // BAM bytes per record (kept until the output is written)
     std::vector<mgx_rec_t> recs; std::vector<uint32_t> input_index;   // arrival order inside the slice
@@ -107,8 +107,8 @@ void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64
         // sized from the text so that the vectors do not grow by doubling (a record is rarely under 100 bytes of text)
         const size_t est = size / 100 + 16;
         c->flag.reserve(est); c->tid.reserve(est); c->pos.reserve(est); c->end.reserve(est);
-        c->cigar_off.reserve(est + 1); c->qual_off.reserve(est + 1); c->qname_off.reserve(est + 1); c->blob_off.reserve(est + 1);
-        c->cigar.reserve(est * 2); c->qual.reserve(size / 2); c->qname.reserve(size / 4); c->blob.reserve(size);
+        c->cigar_off.reserve(est + 1); c->score.reserve(est); c->qname_off.reserve(est + 1); c->blob_off.reserve(est + 1);
+        c->cigar.reserve(est * 2); c->qname.reserve(size / 4); c->blob.reserve(size);
     }
     while (off < hi) {
         const char* nl = (const char*)memchr(data + off, '\n', hi - off);
@@ -117,12 +117,12 @@ void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64
         if (len && data[off + len - 1] == '\r') --len;
         if (len) {
             samtext::Parsed pr;
-            if (!samtext::parse_record_into(data + off, len, h, &pr, &c->cigar, &c->qual, &c->qname, &c->blob, &c->err)) {
+            if (!samtext::parse_record_into(data + off, len, h, &pr, &c->cigar, nullptr, &c->qname, &c->blob, &c->err)) {
                 c->err += " at: " + std::string(data + off, std::min<size_t>(len, 80));
                 return;
             }
             c->flag.push_back(pr.flag); c->tid.push_back(pr.tid); c->pos.push_back(pr.pos); c->end.push_back(pr.end);
-            c->cigar_off.push_back(c->cigar.size()); c->qual_off.push_back(c->qual.size()); c->qname_off.push_back(c->qname.size());
+            c->cigar_off.push_back(c->cigar.size()); c->score.push_back(pr.score); c->qname_off.push_back(c->qname.size());
             c->blob_off.push_back(c->blob.size());
         }
         off = next;
@@ -130,16 +130,16 @@ void parse_slice(const char* data, size_t size, const samtext::Header& h, uint64
     const size_t n = c->flag.size();
     mgx_raw_records_t raw{};
     raw.n_records = n; raw.flag = c->flag.data(); raw.tid = c->tid.data(); raw.pos = c->pos.data();
-    raw.cigar_off = c->cigar_off.data(); raw.cigar = c->cigar.data(); raw.qual_off = c->qual_off.data(); raw.qual = c->qual.data();
+    raw.cigar_off = c->cigar_off.data(); raw.cigar = c->cigar.data(); raw.qual_off = nullptr; raw.qual = nullptr;      // the score comes from the parser
     raw.qname_off = c->qname_off.data(); raw.qname = c->qname.data();
     raw.n_targets = (uint32_t)h.ref_len.size(); raw.target_len = h.ref_len.data();
     c->recs.resize(n); c->input_index.resize(n);
     uint64_t L = 0;
-    if (mgx_sortdedup_pack(&raw, c->recs.data(), c->input_index.data(), &L)) { c->err = std::string("pack: ") + mgx_last_error(); return; }
+    if (mgx_sortdedup_pack_scored(&raw, c->score.data(), c->recs.data(), c->input_index.data(), &L)) { c->err = std::string("pack: ") + mgx_last_error(); return; }
     (void)L_expected;
     // the parse-time arrays are not needed any more (the keys are in recs); keep what the writer needs
-    std::vector<uint32_t>().swap(c->cigar); std::vector<uint8_t>().swap(c->qual); std::vector<char>().swap(c->qname);
-    std::vector<uint64_t>().swap(c->cigar_off); std::vector<uint64_t>().swap(c->qual_off); std::vector<uint64_t>().swap(c->qname_off);
+    std::vector<uint32_t>().swap(c->cigar); std::vector<uint16_t>().swap(c->score); std::vector<char>().swap(c->qname);
+    std::vector<uint64_t>().swap(c->cigar_off); std::vector<uint64_t>().swap(c->qname_off);
 }
 
 }  // namespace
@@ -349,51 +349,74 @@ int main(int argc, char** argv) {
             ++next_commit;
         }
     };
+    auto gpu_state_now = [&]() -> int { std::lock_guard<std::mutex> lk(gpu_mu); return gpu_state; };
+    // what a parsed slice still needs of the device: its BAM bytes into the record store, the writer's view of its records, the
+    // in-order commit (upload of the packed records)
+    auto finish_chunk = [&](std::unique_ptr<Chunk> ch, uint64_t seq) -> bool {
+        if (store) {                                    // the slice's BAM bytes go to HBM now and leave host memory
+            if (mgx_bgzf_store_put(store, ch->blob.data(), ch->blob.size(), &ch->dev_base)) { fail(std::string("GPU: ") + mgx_last_error()); return false; }
+            std::vector<uint8_t>().swap(ch->blob);
+        }
+        {
+            // the writer's view of every record, in the slice's arrival order; the parse-time arrays die here
+            const size_t n = ch->recs.size();
+            ch->kept.resize(n);
+            for (size_t k = 0; k < n; ++k) {
+                const uint32_t src = ch->input_index[k];
+                const uint8_t* where = store ? (const uint8_t*)(uintptr_t)(ch->dev_base + ch->blob_off[src]) : ch->blob.data() + ch->blob_off[src];
+                ch->kept[k] = Kept{where, (uint32_t)(ch->blob_off[src + 1] - ch->blob_off[src]), ch->tid[src], (int32_t)ch->pos[src], ch->end[src],
+                                   (ch->flag[src] & 4) == 0};
+            }
+            std::vector<uint32_t>().swap(ch->input_index);
+            std::vector<uint16_t>().swap(ch->flag); std::vector<int32_t>().swap(ch->tid); std::vector<int64_t>().swap(ch->pos);
+            std::vector<int32_t>().swap(ch->end); std::vector<uint64_t>().swap(ch->blob_off);
+        }
+        std::vector<std::vector<mgx_rec_t>> trash;
+        {
+            std::lock_guard<std::mutex> g(commit_mu);
+            ready.emplace(seq, std::move(ch));
+            commit_ready(&trash);
+        }
+        return !failed.load();
+    };
     auto worker = [&]() {
         std::vector<char> text_buf;                          // this thread's slice of the input file
+        // The HIP runtime and the contexts take 0.2-0.3 s to come up: until then a parser keeps its parsed slices and goes on with
+        // the next one instead of waiting with one slice in hand (round 3: at 4 M records the parse itself is 0.05 s of thread
+        // time per thread -- the ingest was the bring-up plus everything that waited for it)
+        std::vector<std::pair<uint64_t, std::unique_ptr<Chunk>>> waiting;
         for (;;) {
             Slice sl;
+            bool have = false;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return !queue.empty() || done_reading || failed.load(); });
-                if (failed.load() || (queue.empty() && done_reading)) return;
-                sl = std::move(queue.front());
-                queue.pop_front();
-                cv_room.notify_one();
-            }
-            std::unique_ptr<Chunk> ch(new Chunk);
-            if (sl.from_file) {
-                if (text_buf.size() < sl.file_len) text_buf.resize(sl.file_len);
-                if (!pread_all(in_fd, text_buf.data(), sl.file_len, sl.file_off)) { fail("read error on the input file"); return; }
-                parse_slice(text_buf.data(), sl.file_len, hdr, L, ch.get());
-            } else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
-            std::string().swap(sl.text);
-            if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
-            if (!gpu_ready()) { fail("GPU: " + gpu_error); return; }
-            if (store) {                                    // the slice's BAM bytes go to HBM now and leave host memory
-                if (mgx_bgzf_store_put(store, ch->blob.data(), ch->blob.size(), &ch->dev_base)) { fail(std::string("GPU: ") + mgx_last_error()); return; }
-                std::vector<uint8_t>().swap(ch->blob);
-            }
-            {
-                // the writer's view of every record, in the slice's arrival order; the parse-time arrays die here
-                const size_t n = ch->recs.size();
-                ch->kept.resize(n);
-                for (size_t k = 0; k < n; ++k) {
-                    const uint32_t src = ch->input_index[k];
-                    const uint8_t* where = store ? (const uint8_t*)(uintptr_t)(ch->dev_base + ch->blob_off[src]) : ch->blob.data() + ch->blob_off[src];
-                    ch->kept[k] = Kept{where, (uint32_t)(ch->blob_off[src + 1] - ch->blob_off[src]), ch->tid[src], (int32_t)ch->pos[src], ch->end[src],
-                                       (ch->flag[src] & 4) == 0};
+                if (failed.load()) return;
+                if (!queue.empty()) {
+                    sl = std::move(queue.front());
+                    queue.pop_front();
+                    cv_room.notify_one();
+                    have = true;
                 }
-                std::vector<uint32_t>().swap(ch->input_index);
-                std::vector<uint16_t>().swap(ch->flag); std::vector<int32_t>().swap(ch->tid); std::vector<int64_t>().swap(ch->pos);
-                std::vector<int32_t>().swap(ch->end); std::vector<uint64_t>().swap(ch->blob_off);
             }
-            std::vector<std::vector<mgx_rec_t>> trash;
-            {
-                std::lock_guard<std::mutex> g(commit_mu);
-                ready.emplace(sl.seq, std::move(ch));
-                commit_ready(&trash);
+            std::unique_ptr<Chunk> ch;
+            if (have) {
+                ch.reset(new Chunk);
+                if (sl.from_file) {
+                    if (text_buf.size() < sl.file_len) text_buf.resize(sl.file_len);
+                    if (!pread_all(in_fd, text_buf.data(), sl.file_len, sl.file_off)) { fail("read error on the input file"); return; }
+                    parse_slice(text_buf.data(), sl.file_len, hdr, L, ch.get());
+                } else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
+                std::string().swap(sl.text);
+                if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
+                if (gpu_state_now() == 0) { waiting.emplace_back(sl.seq, std::move(ch)); continue; }
             }
+            if (!have && waiting.empty()) return;           // the input is used up and nothing of this thread's waits
+            if (!gpu_ready()) { fail("GPU: " + gpu_error); return; }
+            for (auto& w : waiting) if (!finish_chunk(std::move(w.second), w.first)) return;
+            waiting.clear();
+            if (have) { if (!finish_chunk(std::move(ch), sl.seq)) return; }
+            else return;
         }
     };
     std::vector<std::thread> pool;

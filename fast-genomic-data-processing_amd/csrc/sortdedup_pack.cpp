@@ -54,6 +54,11 @@ uint64_t unclipped_five_prime(uint64_t coord, bool forward, const uint32_t* ciga
 
 // strtol(token, &end, 10) truncated to 16 bits, as str_to_uint16 does (pair.cpp:11-19)
 inline uint16_t token_to_u16(const char* s, size_t len) {
+    if (len > 0 && len <= 18) {                      // all digits, no overflow: what strtol returns, without the call
+        uint64_t v = 0; size_t i = 0;
+        for (; i < len; ++i) { const unsigned d = (unsigned)(s[i] - '0'); if (d > 9) break; v = v * 10 + d; }
+        if (i == len) return (uint16_t)v;
+    }
     char buf[64];
     if (len >= sizeof buf) len = sizeof buf - 1;
     memcpy(buf, s, len);
@@ -84,14 +89,19 @@ void tile_x_y(const char* q, uint64_t len, uint16_t out[3]) {
 
 extern "C" int mgx_sortdedup_pack(const mgx_raw_records_t* raw, mgx_rec_t* out, uint32_t* out_input_index,
                                   uint64_t* out_L) {
+    return mgx_sortdedup_pack_scored(raw, nullptr, out, out_input_index, out_L);
+}
+
+extern "C" int mgx_sortdedup_pack_scored(const mgx_raw_records_t* raw, const uint16_t* score, mgx_rec_t* out, uint32_t* out_input_index,
+                                         uint64_t* out_L) {
     if (!raw || !out_L || (raw->n_records && (!out || !out_input_index))) { mgx::set_error("NULL argument"); return -EINVAL; }
     const uint64_t n = raw->n_records;
     if (n >= 0xFFFFFFFFull) { mgx::set_error("more than 2^32-1 records"); return -E2BIG; }
-    if (n && (!raw->flag || !raw->tid || !raw->pos || !raw->cigar_off || !raw->qual_off || !raw->qname_off ||
+    if (n && (!raw->flag || !raw->tid || !raw->pos || !raw->cigar_off || (!score && !raw->qual_off) || !raw->qname_off ||
               (raw->n_targets && !raw->target_len))) { mgx::set_error("NULL array in raw records"); return -EINVAL; }
     // offsets index host memory: a decreasing table would turn into an out-of-bounds read below
     for (uint64_t r = 0; r < n; ++r)
-        if (raw->cigar_off[r + 1] < raw->cigar_off[r] || raw->qual_off[r + 1] < raw->qual_off[r] || raw->qname_off[r + 1] < raw->qname_off[r]) {
+        if (raw->cigar_off[r + 1] < raw->cigar_off[r] || (!score && raw->qual_off[r + 1] < raw->qual_off[r]) || raw->qname_off[r + 1] < raw->qname_off[r]) {
             mgx::set_error("record %llu: offset table is not monotonic", (unsigned long long)r);
             return -EINVAL;
         }
@@ -114,7 +124,7 @@ extern "C" int mgx_sortdedup_pack(const mgx_raw_records_t* raw, mgx_rec_t* out, 
         o.flag = raw->flag[r];
         o.prime5 = unclipped_five_prime(o.coord, (o.flag & 0x10) == 0, raw->cigar + raw->cigar_off[r],
                                         raw->cigar_off[r + 1] - raw->cigar_off[r]);
-        o.score = base_quality_score(raw->qual + raw->qual_off[r], raw->qual_off[r + 1] - raw->qual_off[r]);
+        o.score = score ? score[r] : base_quality_score(raw->qual + raw->qual_off[r], raw->qual_off[r + 1] - raw->qual_off[r]);
         uint16_t t[3];
         tile_x_y(raw->qname + raw->qname_off[r], qlen(r), t);
         o.tile = t[0]; o.x = t[1]; o.y = t[2];

@@ -145,6 +145,7 @@ SORTDEDUP_SYMBOLS = {
     "mgx_sortdedup_upload_shard": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(SortDedupShard)]),
     "mgx_sortdedup_merge": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgx_sortdedup_pack": (C.c_int, [C.POINTER(RawRecords), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "mgx_sortdedup_pack_scored": (C.c_int, [C.POINTER(RawRecords), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "mgx_sortdedup_create": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
     "mgx_sortdedup_destroy": (None, [C.c_void_p]),
     "mgx_sortdedup_upload": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),

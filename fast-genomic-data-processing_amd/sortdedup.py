@@ -16,9 +16,10 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def pack(raw):
+def pack(raw, score=None):
     """raw: dict of arrays in the layout of mgx_raw_records_t (see synth.RawRecords.arrays()).
-    Returns (recs [arrival order, REC_DTYPE], input_index [arrival -> input], L)."""
+    score: optional uint16 [n], BAMRecord::score per record from the caller's own pass over the qualities
+    (mgx_sortdedup_pack_scored).  Returns (recs [arrival order, REC_DTYPE], input_index [arrival -> input], L)."""
     lib = native.load()
     n = int(raw["n_records"])
     keep = {k: np.ascontiguousarray(raw[k]) for k in
@@ -31,7 +32,14 @@ def pack(raw):
     recs = np.zeros(n, dtype=REC_DTYPE)
     idx = np.zeros(n, dtype=np.uint32)
     L = C.c_uint64()
-    native.check(lib.mgx_sortdedup_pack(C.byref(rr), _ptr(recs), _ptr(idx), C.byref(L)))
+    if score is None:
+        native.check(lib.mgx_sortdedup_pack(C.byref(rr), _ptr(recs), _ptr(idx), C.byref(L)))
+    else:
+        score = np.ascontiguousarray(score, dtype=np.uint16)
+        if len(score) != n:
+            raise ValueError("score needs one entry per record")
+        rr.qual_off = None; rr.qual = None              # mgx_sortdedup_pack_scored does not look at the qualities
+        native.check(lib.mgx_sortdedup_pack_scored(C.byref(rr), _ptr(score), _ptr(recs), _ptr(idx), C.byref(L)))
     return recs, idx, int(L.value)
 
 

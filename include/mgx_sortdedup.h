@@ -89,6 +89,11 @@ typedef struct mgx_sortdedup_stats {
  * out_input_index[k] = index in `raw` of arrival record k.  *out_L = sum of target lengths. */
 int mgx_sortdedup_pack(const mgx_raw_records_t* raw, mgx_rec_t* out_recs, uint32_t* out_input_index,
                        uint64_t* out_L);
+/* The same for a caller that has each record's BAMRecord::score at hand (sortmardup/tbb/bam_record.cpp:7-14: the base qualities
+ * of at least 15 summed in a uint16_t) -- a SAM reader passes over every quality character anyway: score[n] replaces the scan of
+ * raw->qual, and raw->qual / raw->qual_off may then be NULL.  score == NULL is mgx_sortdedup_pack. */
+int mgx_sortdedup_pack_scored(const mgx_raw_records_t* raw, const uint16_t* score, mgx_rec_t* out_recs, uint32_t* out_input_index,
+                              uint64_t* out_L);
 
 /* flags: MGX_CU_PATTERN(p) and MGX_STREAM_HIGH_PRIORITY as for mgx_pairhmm_create (mgx_pairhmm.h), 0 otherwise */
 int mgx_sortdedup_create(int device, unsigned flags, mgx_sortdedup_t** out);

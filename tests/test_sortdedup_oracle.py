@@ -101,3 +101,22 @@ def test_pack_rejects_decreasing_offsets(pkg, synth):
     import pytest
     with pytest.raises(pkg.MgxError, match="monotonic"):
         pkg.sortdedup.pack(bad)
+
+
+def test_pack_with_the_callers_scores(pkg, synth):
+    """mgx_sortdedup_pack_scored: a SAM reader that passes over every quality character anyway hands in
+    BAMRecord::score per record (qualities of at least 15 summed in 16 bits, wrapping); the records equal those of
+    mgx_sortdedup_pack, which scans the qualities itself -- also for sums beyond 65 535"""
+    for seed, n in ((3, 1200), (4, 1)):
+        raw = synth.gen_sortdedup_raw(n, seed, dup_rate=0.3, frag_rate=0.1, supp_rate=0.05)
+        q = np.asarray(raw["qual"], dtype=np.uint8).copy()
+        if seed == 3:
+            q[: len(q) // 3] = 93                   # long runs of the highest quality: the 16-bit sum wraps
+            raw["qual"] = q
+        off = np.asarray(raw["qual_off"], dtype=np.int64)
+        vals = np.where(q >= 15, q, 0).astype(np.int64)
+        cs = np.concatenate([[0], np.cumsum(vals)])
+        score = ((cs[off[1:]] - cs[off[:-1]]) & 0xFFFF).astype(np.uint16)
+        want, widx, wl = pkg.sortdedup.pack(raw)
+        got, gidx, gl = pkg.sortdedup.pack(raw, score=score)
+        assert np.array_equal(got, want) and np.array_equal(gidx, widx) and gl == wl
