@@ -7,7 +7,10 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "sam_text.h"
@@ -15,6 +18,19 @@
 namespace bamout {
 
 // (encode_record, kFlagOffset and reg2bin live next to the parser: sam_text.h)
+
+// std::vector whose resize() / sized constructor leaves trivial elements uninitialised: an array of 200 M records is several GB,
+// and value-initialising it is one thread writing zeros to all of it (and touching every page first) before the threads that
+// fill it start -- 1-2 s per array at BASELINE configs[3]
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    default_init_allocator() = default;
+    template <class U> default_init_allocator(const default_init_allocator<U>&) {}
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using NoInitVector = std::vector<T, default_init_allocator<T>>;
 
 struct RecordRef {              // one record of the output, in output order
     const uint8_t* blob;        // encode_record() bytes
@@ -24,16 +40,18 @@ struct RecordRef {              // one record of the output, in output order
     bool mapped;                // !(flag & 4), for the index metadata
 };
 
+using RecordRefs = NoInitVector<RecordRef>;
+
 // Writes <path> and <path>.bai.  Returns false and sets *err on I/O failure.
 // device >= 0: the BGZF blocks are compressed on that HIP device (include/mgx_bgzf.h), the writer threads only gather
 // the records; device < 0: zlib at `level` on the writer threads (the reference's way, bgzf.c:610).
-bool write_bam(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs,
+bool write_bam(const std::string& path, const samtext::Header& hdr, const RecordRefs& recs,
                int threads, int level, int device, std::string* err);
 
 // The same with the records resident in HBM: recs[k].blob is the DEVICE address mgx_bgzf_store_put() returned for the
 // record; bgzf_ctx / store are the mgx_bgzf_t* / mgx_bgzf_store_t* that hold them (include/mgx_bgzf.h).  The device gathers
 // the records in output order, sets the duplicate flags, cuts and compresses the stream; the host writes blocks and index.
-bool write_bam_store(const std::string& path, const samtext::Header& hdr, const std::vector<RecordRef>& recs, void* bgzf_ctx, void* store,
+bool write_bam_store(const std::string& path, const samtext::Header& hdr, const RecordRefs& recs, void* bgzf_ctx, void* store,
                      int threads, std::string* err);
 
 }  // namespace bamout

@@ -319,7 +319,7 @@ int main(int argc, char** argv) {
     std::map<uint64_t, std::unique_ptr<Chunk>> ready;
     uint64_t next_commit = 0, n_total = 0;
     std::vector<std::unique_ptr<Chunk>> kept_chunks;         // committed slices: their writer records, and (not -z device) the BAM bytes
-    std::vector<Kept> by_arrival;                            // flattened after the ingest
+    bamout::NoInitVector<Kept> by_arrival;                   // flattened after the ingest (its pages first touched by the copying gang)
     auto fail = [&](const std::string& msg) {
         std::lock_guard<std::mutex> g(mu);
         if (!failed.exchange(true)) first_error = msg;
@@ -515,7 +515,7 @@ int main(int argc, char** argv) {
     if (getenv("MGX_CLI_TRACE")) fprintf(stderr, "  ingest: %.3f s inside the in-order commit (one thread at a time), %.3f s of it in mgx_sortdedup_upload_chunk\n", commit_seconds, upload_seconds);
 
     if (mgx_sortdedup_upload_end(sd, n)) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
-    std::vector<uint32_t> order(n); std::vector<uint8_t> dup(n);
+    bamout::NoInitVector<uint32_t> order(n); bamout::NoInitVector<uint8_t> dup(n);
     if (mgx_sortdedup_run(sd) || mgx_sortdedup_results(sd, order.data(), dup.data())) { fprintf(stderr, "GPU: %s\n", mgx_last_error()); return 1; }
     mgx_sortdedup_stats_t st{};
     mgx_sortdedup_stats(sd, &st);
@@ -525,7 +525,7 @@ int main(int argc, char** argv) {
     time_stamp("sort + duplicate search done");
 
     // ---- mark + compress + write
-    std::vector<bamout::RecordRef> out(n);
+    bamout::RecordRefs out(n);
     {
         // a gather with random reads from by_arrival: spread over the threads
         std::vector<std::thread> gang;

@@ -260,6 +260,26 @@ def test_cli_device_and_zlib_deflate_hold_the_same_stream(tmp_path, synth):
 
 
 @pytest.mark.gpu
+def test_cli_index_built_in_parts_and_file_written_by_helpers(tmp_path, synth):
+    """round 3: the BAI of a large output is built in contiguous parts on several threads and merged (the serial index byte for
+    byte: a bin's chunks joined across the seams, linear windows by minimum), and the BAM is written by the thread that
+    receives the blocks; MGX_CLI_BAI_PARTS forces the parts on a small input, MGX_CLI_WRITERS the helper threads of rounds 1-2:
+    same .bam, same .bai"""
+    raw = synth.gen_sortdedup_raw(9000, 78, n_contigs=5, contig_len=200000, dup_rate=0.2, frag_rate=0.05, supp_rate=0.03)
+    sam = str(tmp_path / "in.sam")
+    make_sam(raw, sam)
+    out = {}
+    for tag, env in (("serial", {}), ("parts7", {"MGX_CLI_BAI_PARTS": "7"}), ("parts64", {"MGX_CLI_BAI_PARTS": "64"}), ("helpers", {"MGX_CLI_WRITERS": "3"})):
+        bam = str(tmp_path / f"{tag}.bam")
+        res = subprocess.run([build_cli(), "-I", sam, "-O", bam, "-t", "8"], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert res.returncode == 0, res.stderr
+        out[tag] = (open(bam, "rb").read(), open(bam + ".bai", "rb").read())
+    assert len(out["serial"][1]) > 500
+    for tag in ("parts7", "parts64", "helpers"):
+        assert out[tag] == out["serial"], tag
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("deflate", ["device", "pinned", "zlib"])
 def test_cli_header_only_input(tmp_path, deflate):
     """no alignment records at all: a BAM with the header, the end-of-file block and an index without entries"""
