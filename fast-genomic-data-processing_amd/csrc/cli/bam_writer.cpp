@@ -22,6 +22,8 @@
 
 namespace bamout {
 
+std::atomic<int> g_store_arrays_ready{0};
+
 namespace {
 
 constexpr size_t kBlockIn = 0xff00;          // uncompressed bytes per BGZF block
@@ -524,6 +526,7 @@ bool write_bam_store(const std::string& path, const samtext::Header& hdr, const 
             });
         for (auto& th : gang) th.join();
     }
+    g_store_arrays_ready.store(1);
     stamp("arrays ready");
     // The sink must be done with a batch's bytes when it returns.  Round 3: it simply writes them -- one pwrite of the whole batch
     // from the pinned buffer, on the thread store_emit calls it on.  The device does not wait for that (store_emit keeps three

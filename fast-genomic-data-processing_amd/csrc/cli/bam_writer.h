@@ -6,6 +6,7 @@
 // independent BGZF blocks, concatenation, and a BAI index built from the records' virtual offsets.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -41,6 +42,10 @@ struct RecordRef {              // one record of the output, in output order
 };
 
 using RecordRefs = NoInitVector<RecordRef>;
+
+// set to 1 by write_bam_store once its per-record arrays are built (the caller's clean-up thread waits for that: page frees and
+// first touches of 5 GB of new arrays slow each other down)
+extern std::atomic<int> g_store_arrays_ready;
 
 // Writes <path> and <path>.bai.  Returns false and sets *err on I/O failure.
 // device >= 0: the BGZF blocks are compressed on that HIP device (include/mgx_bgzf.h), the writer threads only gather

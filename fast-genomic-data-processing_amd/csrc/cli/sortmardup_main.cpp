@@ -540,9 +540,26 @@ int main(int argc, char** argv) {
             });
         for (auto& th : gang) th.join();
     }
+    // what the output stage no longer needs goes back to the kernel on a thread of its own while the stream is written (at 200 M
+    // records: 7 GB of per-record bookkeeping that would otherwise be torn down after the last byte is on disk)
+    // (madvise, not free: unmapping takes the address space's lock for writing for as long as it frees pages, and the output
+    // stage's threads are first-touching their own arrays right now; dropping the pages only needs it for reading)
+    std::atomic<bool> writer_returned{false};
+    std::thread reaper([&]() {
+        while (store && !bamout::g_store_arrays_ready.load() && !writer_returned.load()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        auto drop = [](void* p, size_t bytes) {
+            const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+            if (e > a) (void)madvise((void*)a, e - a, MADV_DONTNEED);
+        };
+        drop(by_arrival.data(), by_arrival.size() * sizeof(Kept));
+        drop(order.data(), order.size() * sizeof(uint32_t));
+        drop(dup.data(), dup.size());
+    });
     std::string err;
     const bool wrote = store ? bamout::write_bam_store(out_path, hdr, out, zctx, store, threads, &err)
                              : bamout::write_bam(out_path, hdr, out, threads, level, out_mode == kOutPinned ? device : -1, &err);
+    writer_returned.store(true);
+    reaper.join();
     if (!wrote) { fprintf(stderr, "write: %s\n", err.c_str()); return 1; }
     time_stamp("output done");
     // Both files are closed.  What is left is tearing down ~N small records' bookkeeping, the arenas and the HIP runtime --
