@@ -409,7 +409,8 @@ int main(int argc, char** argv) {
                 } else parse_slice(sl.text.data(), sl.text.size(), hdr, L, ch.get());
                 std::string().swap(sl.text);
                 if (!ch->err.empty()) { fail("SAM parse error: " + ch->err); return; }
-                if (gpu_state_now() == 0) { waiting.emplace_back(sl.seq, std::move(ch)); continue; }
+                // (bounded: 32 slices per thread are ~200 MB of parsed records; a device that takes longer than that to come up is waited for)
+                if (waiting.size() < 32 && gpu_state_now() == 0) { waiting.emplace_back(sl.seq, std::move(ch)); continue; }
             }
             if (!have && waiting.empty()) return;           // the input is used up and nothing of this thread's waits
             if (!gpu_ready()) { fail("GPU: " + gpu_error); return; }

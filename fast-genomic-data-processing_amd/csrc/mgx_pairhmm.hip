@@ -1306,7 +1306,8 @@ int mgx_pairhmm_compute_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_
     // A large call is cut into runs of whole regions of about kChunkPairs test cases that go through the context two
     // at a time: while one chunk computes, the next is flattened and uploaded and the previous one's results are
     // scattered -- the queue's pipelining (mgx_pairhmm_queue_run_regions) on the caller's thread alone.
-    constexpr uint64_t kChunkPairs = 1u << 17;
+    uint64_t kChunkPairs = 1u << 17;
+    if (const char* e = getenv("MGX_PAIRHMM_REGION_CHUNK")) { const long long v = atoll(e); if (v > 0) kChunkPairs = (uint64_t)v; }      // A/B
     std::vector<uint32_t> cut(1, 0);
     {
         uint64_t in_chunk = 0;
