@@ -13,7 +13,16 @@
 //   * CIGAR text and its capacity rule (host, next to the caller's buffer): PairWiseSW.h:410-444
 //
 // Back-trace bytes are laid out by (step, lane, row-in-lane) so that one step of a wavefront stores
-// 64 * RPL consecutive bytes; the trace kernel (one lane per pair) converts (i, j) back to that index.
+// 64 * RPL consecutive bytes; the trace kernels convert (i, j) back to that index (BtView).
+//
+// Two fill kernels (round 3):
+//   k_sw_fill16   packed 16-bit scores, two pairs per lane group, the four decisions of a cell taken from the sign bits of four
+//                 packed differences, back-trace nibbles, all row classes in one launch -- for every pair whose scores provably fit
+//                 16 bits (I16Rule; the realignment workload of Mutect2 always does): 12.6 instructions per cell
+//   k_sw_fill     32-bit scores, one pair per lane group, compare + select per decision, back-trace bytes, one launch per row class
+//                 -- everything else (long references with long alternates, large scoring parameters); optionally with the lanes
+//                 over the alternate sequence (TR; measured slower, opt-in)
+// Both write what the trace kernels read through BtView / LastRow / LastCol; a batch may mix them pair by pair.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
