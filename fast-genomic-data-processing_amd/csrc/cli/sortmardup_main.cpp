@@ -190,13 +190,31 @@ int main(int argc, char** argv) {
 #endif
     setvbuf(f, nullptr, _IONBF, 0);                          // read_more() asks for megabytes at a time: no second buffer
 
-    // A regular file is read by the parser threads themselves (pread of their own slice into their own buffer): the
-    // reader only looks at a few KB around every cut to place it on a queryname-group boundary.  (Mapping the file
-    // instead cost 1.8 M page faults per 7 GB and made the ingest time vary by 50 % from run to run.)  stdin goes
-    // through read() and owned slices.
+    // A regular file is read by the parser threads themselves (their own slice, in place from a populated mapping -- below -- or
+    // by pread into their own buffer): the reader only looks at a few KB around every cut to place it on a queryname-group
+    // boundary.  (Mapping the file and letting every page fault on its own cost 1.8 M page faults per 7 GB and made the ingest time
+    // vary by 50 % from run to run.)  stdin goes through read() and owned slices.
     const int in_fd = (in_path && file_bytes) ? fileno(f) : -1;
     const bool map = in_fd >= 0;
     const size_t map_size = (size_t)file_bytes;
+    // Round 3: the parsers read their slice IN PLACE from a mapping of the file, after one madvise(MADV_POPULATE_READ) per slice has
+    // the kernel fill in its page-table entries (2048 of them in one call, no fault per page), instead of copying the slice out of
+    // the page cache with pread: 200 M records ingest 5.7 -> 4.5-5.1 s on one box.  MGX_CLI_MMAP_IN=0, a kernel without
+    // MADV_POPULATE_READ or a file that cannot be mapped keep the pread path.
+    const char* in_base = nullptr;
+#ifdef MADV_POPULATE_READ
+    {
+        const char* e = getenv("MGX_CLI_MMAP_IN");
+        if (map && (!e || atoi(e) != 0)) {
+            void* mp = mmap(nullptr, map_size, PROT_READ, MAP_SHARED, in_fd, 0);
+            if (mp != MAP_FAILED) {
+                // is the advice known to this kernel? (EINVAL on kernels before 5.14)
+                if (madvise(mp, std::min<size_t>(map_size, 4096), MADV_POPULATE_READ) == 0) in_base = static_cast<const char*>(mp);
+                else (void)munmap(mp, map_size);
+            }
+        }
+    }
+#endif
     auto pread_all = [](int fd, char* dst, size_t n, uint64_t at) -> bool {
         while (n) {
             const ssize_t g = pread(fd, dst, n, (off_t)at);
@@ -402,7 +420,14 @@ int main(int argc, char** argv) {
             std::unique_ptr<Chunk> ch;
             if (have) {
                 ch.reset(new Chunk);
-                if (sl.from_file) {
+                if (sl.from_file && in_base) {
+#ifdef MADV_POPULATE_READ
+                    const uintptr_t a0 = (uintptr_t)(in_base + sl.file_off) & ~(uintptr_t)4095, a1 = ((uintptr_t)(in_base + sl.file_off + sl.file_len) + 4095) & ~(uintptr_t)4095;
+                    (void)madvise((void*)a0, a1 - a0, MADV_POPULATE_READ);
+                    parse_slice(in_base + sl.file_off, sl.file_len, hdr, L, ch.get());
+                    (void)madvise((void*)a0, a1 - a0, MADV_DONTNEED);      // drops this process's entries only: the pages stay in the page cache
+#endif
+                } else if (sl.from_file) {
                     if (text_buf.size() < sl.file_len) text_buf.resize(sl.file_len);
                     if (!pread_all(in_fd, text_buf.data(), sl.file_len, sl.file_off)) { fail("read error on the input file"); return; }
                     parse_slice(text_buf.data(), sl.file_len, hdr, L, ch.get());
