@@ -1303,13 +1303,21 @@ int mgx_pairhmm_compute_regions(mgx_pairhmm_t* c, uint32_t n_regions, const mgx_
         if (regions[g].n_reads * regions[g].n_haps && !out_log10[g]) { set_error("region %u: output pointer is NULL", g); return -EINVAL; }
     }
     HIP_TRY(hipSetDevice(c->device));
-    // A large call is cut into runs of whole regions of about kChunkPairs (196 608) test cases that go through the context two
+    // A large call is cut into runs of whole regions of about kChunkPairs (196 608 to 393 216) test cases that go through the context two
     // at a time: while one chunk computes, the next is flattened and uploaded and the previous one's results are
     // scattered -- the queue's pipelining (mgx_pairhmm_queue_run_regions) on the caller's thread alone.
     // (tools/dev_regions_chunk.py, 1000 regions of 40 x 25 on an MI355X: 65 536 test cases per chunk 2 430 GCUPS, 131 072 3 035,
     // 196 608 3 193, 262 144 2 980-3 190, 524 288 2 610, one chunk 2 090: larger chunks mean larger class launches, fewer of them
     // mean less of the flattening hidden behind the kernels)
+    // Larger jobs take larger chunks (a sixth of the job, at most 393 216 test cases): 1000 regions of 100 x 50 (5 M test cases)
+    // 3 440 GCUPS with 131 072 per chunk, 3 790 with 196 608, 4 160 with 393 216, 3 960 with 524 288; 200 regions of 300 x 100:
+    // 3 640 / 4 050 / 4 560 / 4 370; 4000 regions of 40 x 25: 3 460 with 196 608, 3 620 with 393 216 (tools/dev_regions_chunk_shapes.py)
     uint64_t kChunkPairs = 3u << 16;
+    {
+        uint64_t total = 0;
+        for (uint32_t g = 0; g < n_regions; ++g) total += regions[g].n_reads * regions[g].n_haps;
+        kChunkPairs = std::min<uint64_t>(6u << 16, std::max<uint64_t>(kChunkPairs, total / 6));
+    }
     if (const char* e = getenv("MGX_PAIRHMM_REGION_CHUNK")) { const long long v = atoll(e); if (v > 0) kChunkPairs = (uint64_t)v; }      // A/B
     std::vector<uint32_t> cut(1, 0);
     {
