@@ -488,18 +488,9 @@ __global__ __launch_bounds__(64) void k_sw_trace_wave(const SwJob* __restrict__ 
     // ---- best end cell (PairWiseSW.h:256-285).  The maximum first, in parallel; then the cells that reach it are
     //      replayed in anti-diagonal order (row candidate before column candidate), which is all the tie rules see.
     int best = INT32_MIN;
-    if (use_row) for (int j = 1 + lane; j <= ncol; j += 64) best = max(best, last_row[j]);
-    for (int i = 1 + lane; i <= nrow; i += 64) best = max(best, last_col[i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
     int mi = 0, mj = 0;
     bool have = false;
-    for (int d0 = 1; d0 <= nrow + ncol; d0 += 64) {
-        const int d = d0 + lane;
-        const int ja = d - nrow, ib = d - ncol;
-        const bool eq_a = use_row && d <= nrow + ncol && ja >= 1 && last_row[ja] == best;
-        const bool eq_b = d <= nrow + ncol && ib >= 1 && last_col[ib] == best;
-        const u64 ma = __ballot(eq_a), mb = __ballot(eq_b);
+    auto replay = [&](int d0, u64 ma, u64 mb) {           // the candidates of anti-diagonals d0 .. d0 + 63, in order
         u64 any = ma | mb;
         while (any) {
             const int t = __ffsll((long long)any) - 1;
@@ -513,6 +504,39 @@ __global__ __launch_bounds__(64) void k_sw_trace_wave(const SwJob* __restrict__ 
                 const int i = dd - ncol;
                 if (!have || mj == ncol || abs(i - ncol) <= abs(mi - mj)) { mi = i; mj = ncol; have = true; }
             }
+        }
+    };
+    constexpr int kEdgeRegs = 8;
+    if (nrow + ncol <= 64 * kEdgeRegs) {
+        // the usual case (a read against its haplotype window): both edges fit the wavefront's registers -- all loads issued at
+        // once, the maximum and the replay from registers (round 3; the two-pass form below paid one memory round trip per 64
+        // anti-diagonals in the replay, behind the one for the maximum)
+        int va[kEdgeRegs], vb[kEdgeRegs];
+#pragma unroll
+        for (int q = 0; q < kEdgeRegs; ++q) {
+            const int d = 1 + 64 * q + lane, ja = d - nrow, ib = d - ncol;
+            va[q] = (use_row && d <= nrow + ncol && ja >= 1) ? last_row[ja] : INT32_MIN;      // (no score is INT32_MIN: MATRIX_MIN_CUTOFF bounds them)
+            vb[q] = (d <= nrow + ncol && ib >= 1) ? last_col[ib] : INT32_MIN;
+            best = max(best, max(va[q], vb[q]));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+#pragma unroll
+        for (int q = 0; q < kEdgeRegs; ++q) {
+            if (1 + 64 * q > nrow + ncol) break;
+            replay(1 + 64 * q, __ballot(va[q] == best), __ballot(vb[q] == best));
+        }
+    } else {
+        if (use_row) for (int j = 1 + lane; j <= ncol; j += 64) best = max(best, last_row[j]);
+        for (int i = 1 + lane; i <= nrow; i += 64) best = max(best, last_col[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+        for (int d0 = 1; d0 <= nrow + ncol; d0 += 64) {
+            const int d = d0 + lane;
+            const int ja = d - nrow, ib = d - ncol;
+            const bool eq_a = use_row && d <= nrow + ncol && ja >= 1 && last_row[ja] == best;
+            const bool eq_b = d <= nrow + ncol && ib >= 1 && last_col[ib] == best;
+            replay(d0, __ballot(eq_a), __ballot(eq_b));
         }
     }
     // ---- back-trace (PairWiseSW.h:299-408), elements in run-length form
@@ -543,7 +567,14 @@ __global__ __launch_bounds__(64) void k_sw_trace_wave(const SwJob* __restrict__ 
                 const int ii = i - lane, jj = j - lane;
                 cached = (ii >= 1 && jj >= 1) ? view.cell(ii, jj) : 0;
             }
-            btr = __builtin_amdgcn_readlane(cached, __builtin_amdgcn_readfirstlane(t));
+            const int tt = __builtin_amdgcn_readfirstlane(t);
+            // A run of diagonal matches is consumed in ONE step (round 3): the walk is wave-uniform -- one cell per iteration keeps
+            // 63 lanes idle for ~275 iterations per pair, and that issue time, not the memory, was most of the trace kernel.  Lanes
+            // beyond the matrix hold 0 = a match: the run is bounded by i and j.
+            const u64 rest = ~(__ballot((cached & 3) == kOpMatch) >> tt);
+            const int run = min(rest ? (int)__builtin_ctzll(rest) : 64, min(i, j));
+            if (run > 0) { i -= run; j -= run; push(kOpMatch, run); continue; }
+            btr = __builtin_amdgcn_readlane(cached, tt);
         } else {
             btr = view.cell(i, j);
         }
