@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <cstdint>
@@ -790,11 +791,21 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
         c->pin_cap = total + total / 4;
     }
     char* const pin = static_cast<char*>(c->pin);
+    int rc;
+    if ((rc = c->d_s1.reserve(n1 + 16)) || (rc = c->d_s2.reserve(n2 + 16))) return rc;
+    hipStream_t s = c->stream;
     std::thread stager[2];
     struct Joiner { std::thread* t; ~Joiner() { for (int k = 0; k < 2; ++k) if (t[k].joinable()) t[k].join(); } } joiner{stager};
-    if (n1 + n2 >= (1u << 20)) {
-        stager[0] = std::thread([=] { memcpy(pin, in->ref + base1, n1); });
-        stager[1] = std::thread([=] { memcpy(pin + a1, in->alt + base2, n2); });
+    std::atomic<int> stage_err{0};
+    const bool staged_apart = n1 + n2 >= (1u << 20);
+    if (staged_apart) {
+        // each helper also queues its array's upload as soon as it is staged: the copies cross the link while the jobs are laid out
+        const int dev = c->device;
+        u8* const d1 = c->d_s1.p; u8* const d2 = c->d_s2.p;
+        stager[0] = std::thread([=, &stage_err] { memcpy(pin, in->ref + base1, n1);
+                                                  if (hipSetDevice(dev) != hipSuccess || hipMemcpyAsync(d1, pin, n1, hipMemcpyHostToDevice, s) != hipSuccess) stage_err = 1; });
+        stager[1] = std::thread([=, &stage_err] { memcpy(pin + a1, in->alt + base2, n2);
+                                                  if (hipSetDevice(dev) != hipSuccess || hipMemcpyAsync(d2, pin + a1, n2, hipMemcpyHostToDevice, s) != hipSuccess) stage_err = 1; });
     } else { memcpy(pin, in->ref + base1, n1); memcpy(pin + a1, in->alt + base2, n2); }
     // Per pair in input order: class and admission.  Then launch order: the packed 16-bit classes first (32 lanes, then 64; most
     // rows per lane first), the 32-bit classes after them, longest alternate first inside a class (the two pairs of a lane group
@@ -886,14 +897,15 @@ int run_chunk(mgx_sw* c, const mgx_sw_params_t* params, const mgx_sw_input_t* in
     }
     const u64 scn = n1 + n2 + 2ull * n, eln = 2 * scn;
     tp[1] = now();
-    int rc;
-    if ((rc = c->d_s1.reserve(n1 + 16)) || (rc = c->d_s2.reserve(n2 + 16)) || (rc = c->d_bt.reserve(bt + 16)) || (rc = c->d_jobs.reserve(n_jobs)) ||
+    if ((rc = c->d_bt.reserve(bt + 16)) || (rc = c->d_jobs.reserve(n_jobs)) ||
         (rc = c->d_sc.reserve(scn)) || (rc = c->d_el.reserve(eln)) || (rc = c->d_res.reserve(n)) ||
         (rc = c->d_cel.reserve((size_t)n * 2 * kCompactElems))) return rc;
-    hipStream_t s = c->stream;
     for (auto& t : stager) if (t.joinable()) t.join();
-    HIP_TRY(hipMemcpyAsync(c->d_s1.p, pin, n1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_s2.p, pin + a1, n2, hipMemcpyHostToDevice, s));
+    if (stage_err.load()) { (void)hipGetLastError(); set_error("upload of the sequences failed"); return -EIO; }
+    if (!staged_apart) {
+        HIP_TRY(hipMemcpyAsync(c->d_s1.p, pin, n1, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->d_s2.p, pin + a1, n2, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(hipMemcpyAsync(c->d_jobs.p, jobs, n_jobs * sizeof(SwJob), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(c->ev[0], s));
     tp[2] = now();
