@@ -211,7 +211,9 @@ def sortmardup_leg(pkg, synth, args, rank, local_rank, world, dist, torch, backe
                                     "duration inside the timed three-stream runs"},
                "model_roofline": {"alg_bytes": st["alg_bytes"], "achieved": st["alg_bytes"] / (st["ms_total"] * 1e-3) / 1e9,
                                   "unit": "GB/s", "frac": st["alg_bytes"] / (st["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "note": "LSD-8 traffic model of SURVEY.md 8d (307.5 B/record at this config) over the whole pipeline"}}
+                                  "note": "A MODEL, not a measured bandwidth: the bytes the reference-shaped LSD-8 pipeline of SURVEY.md 8d would move "
+                                          "(307.5 B/record at this config) divided by this pipeline's time -- it runs fewer and narrower passes than the "
+                                          "model (DESIGN.md 4.2), so the figure can exceed what a copy kernel reaches; the measured roof is `roofline`"}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = sort_cpu_baseline(pkg, L, recs)
     eng.close()
