@@ -174,3 +174,24 @@ def test_transposed_fill(sw_engine, sw_oracle, synth, monkeypatch):
         want_c, want_o, want_s = sw_oracle.batch(w, (25, -50, -110, -6))
         got_c, got_o, got_s = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"], want_score=True)
         assert np.array_equal(got_o, want_o) and np.array_equal(got_s, want_s) and got_c == want_c
+
+
+def test_largest_sizes_and_many_chunks(sw_engine, sw_oracle, synth, monkeypatch):
+    """the largest lengths the ABI takes (reference 2048, alternate 32 767: the 32-bit kernel, one pair per chunk-sized
+    arena) and a batch of pairs at the 16-bit kernel's admission edge cut into many chunks by a small arena"""
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = acgt[rng.integers(0, 4, 2048)]
+    alt_long = np.concatenate([acgt[rng.integers(0, 4, 15000)], ref[100:1900], acgt[rng.integers(0, 4, 32767 - 15000 - 1800)]])
+    w = _concat([(ref, alt_long), (ref[:2047], alt_long[:30000]), (ref, ref[5:2040])], [9, 12, 10])
+    want_c, want_o, want_s = sw_oracle.batch(w, (25, -50, -110, -6))
+    got_c, got_o, got_s = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"], want_score=True)
+    assert np.array_equal(got_o, want_o) and np.array_equal(got_s, want_s) and got_c == want_c
+    assert sw_engine.stats()["n_pairs_i16"] == 0
+    monkeypatch.setenv("MGX_SW_ARENA_LIMIT", str(16 << 20))
+    w = synth.gen_sw_pairs(600, 4242, ref_range=(700, 1000), alt_range=(100, 300))
+    want_c, want_o, want_s = sw_oracle.batch(w, (25, -50, -110, -6))
+    got_c, got_o, got_s = sw_engine.align_batch(w["ref_off"], w["ref"], w["alt_off"], w["alt"], w["strategy"], want_score=True)
+    assert np.array_equal(got_o, want_o) and np.array_equal(got_s, want_s) and got_c == want_c
+    st = sw_engine.stats()
+    assert st["n_pairs_i16"] == 600 and st["n_launches"] >= 4
